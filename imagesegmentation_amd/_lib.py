@@ -1,0 +1,250 @@
+"""ctypes binding of libfs_hip.so (C ABI in include/fs_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or
+``make -C imagesegmentation_amd/csrc``).  There is no CPU fallback: if the
+library is missing or no GPU is usable, every entry point raises.
+"""
+import ctypes
+import json
+import os
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfs_hip.so")
+
+_c = ctypes
+_vp, _i, _d = _c.c_void_p, _c.c_int, _c.c_double
+
+# name -> (restype, argtypes); mirrors include/fs_hip.h one to one
+SIGNATURES = {
+    "fs_create": (_i, [_c.POINTER(_vp), _i, _i, _i, _i]),
+    "fs_destroy": (None, [_vp]),
+    "fs_last_error": (_c.c_char_p, [_vp]),
+    "fs_set_view_angles": (_i, [_vp, _d, _d]),
+    "fs_set_gauss_params": (_i, [_vp, _vp]),
+    "fs_set_kernel_size": (_i, [_vp, _i]),
+    "fs_set_stream": (_i, [_vp, _vp]),
+    "fs_stream": (_vp, [_vp]),
+    "fs_smooth_depth": (_i, [_vp, _i, _vp, _vp]),
+    "fs_normals": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_patches": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_connected_components": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "fs_crf_step": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
+    "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
+    "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_set_timing": (_i, [_vp, _i]),
+    "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libfs_hip.so and declare every prototype.  Raises if it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C imagesegmentation_amd/csrc` (there is no CPU fallback)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def gauss_parameters():
+    """load_Gauss_parameters (find_surfaces.py:221-226) from the JSON copy of the
+    shipped float32 values: bias forced to 0, weight 0.01 appended."""
+    with open(os.path.join(_HERE, "params", "gauss.json")) as f:
+        doc = json.load(f)
+    p = [struct.unpack("<f", bytes.fromhex(h))[0] for h in doc["hex"]]
+    p.append(0.01)
+    p[3] = 0
+    return np.asarray(p, np.float32)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    return a.ctypes.data
+
+
+def _arr(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class Context:
+    """One fs_ctx: a GPU, a stream, frame size (H, W) and a maximum batch."""
+
+    def __init__(self, height, width, max_batch=1, device=0, kernel_size=7, params=None):
+        self._lib = load()
+        self._h = _vp()
+        self.H, self.W, self.max_batch, self.device = int(height), int(width), int(max_batch), int(device)
+        if self._lib.fs_create(ctypes.byref(self._h), self.device, self.H, self.W, self.max_batch) != 0:
+            raise RuntimeError("fs_create failed: " + self._lib.fs_last_error(None).decode())
+        self.kernel_size = 7
+        self.set_kernel_size(kernel_size)
+        self.set_gauss_params(gauss_parameters() if params is None else params)
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.fs_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.fs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_gauss_params(self, params):
+        p = _arr(np.asarray(params, np.float32).reshape(-1), np.float32, (13,))
+        self.params = p
+        self._check(self._lib.fs_set_gauss_params(self._h, _ptr(p)))
+
+    def set_kernel_size(self, r):
+        self._check(self._lib.fs_set_kernel_size(self._h, int(r)))
+        self.kernel_size = int(r)
+
+    def set_view_angles(self, view_x, view_y):
+        self._check(self._lib.fs_set_view_angles(self._h, float(view_x), float(view_y)))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.fs_set_stream(self._h, stream_ptr))
+
+    def stream(self):
+        return self._lib.fs_stream(self._h)
+
+    def set_timing(self, on):
+        self._check(self._lib.fs_set_timing(self._h, 1 if on else 0))
+
+    def get_timing(self, group):
+        ms, cnt = _d(0), _c.c_int64(0)
+        self._check(self._lib.fs_get_timing(self._h, group, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    def _batch(self, a, tail=()):
+        a = np.asarray(a)
+        single = a.ndim == 2 + len(tail)
+        if single:
+            a = a[None]
+        if a.shape[1:] != (self.H, self.W) + tuple(tail):
+            raise ValueError(f"expected [n,{self.H},{self.W}{''.join(',%d' % t for t in tail)}], got {a.shape}")
+        return a, single
+
+    # -- stage operators -------------------------------------------------------
+    def smooth_depth(self, depth):
+        d, single = self._batch(depth)
+        d = _arr(d, np.float32)
+        out = np.empty_like(d)
+        self._check(self._lib.fs_smooth_depth(self._h, d.shape[0], _ptr(d), _ptr(out)))
+        return out[0] if single else out
+
+    def normals(self, smoothed, want_raw=False):
+        d, single = self._batch(smoothed)
+        d = _arr(d, np.float32)
+        n = d.shape[0]
+        ang, vec, pts = (np.empty((n, self.H, self.W, c), np.float32) for c in (2, 3, 3))
+        raw = np.empty((n, self.H, self.W, 2), np.float32) if want_raw else None
+        self._check(self._lib.fs_normals(self._h, n, _ptr(d), _ptr(ang), _ptr(vec), _ptr(pts), _ptr(raw)))
+        res = [ang, vec, pts] + ([raw] if want_raw else [])
+        return [a[0] for a in res] if single else res
+
+    def patches(self, smoothed, want_curvature=False):
+        d, single = self._batch(smoothed)
+        d = _arr(d, np.float32)
+        n = d.shape[0]
+        pat, edg = np.empty((n, self.H, self.W), np.int64), np.empty((n, self.H, self.W), np.int32)
+        sc = np.empty((n, self.H, self.W), np.float32) if want_curvature else None
+        cm = np.empty((n, self.H, self.W), np.uint8) if want_curvature else None
+        self._check(self._lib.fs_patches(self._h, n, _ptr(d), _ptr(pat), _ptr(edg), _ptr(sc), _ptr(cm)))
+        res = [pat, edg] + ([sc, cm] if want_curvature else [])
+        return [a[0] for a in res] if single else res
+
+    def connected_components(self, mask, min_size_exclusive=0):
+        m, single = self._batch(mask)
+        m = _arr(m != 0, np.uint8)
+        n = m.shape[0]
+        lab, cnt = np.empty((n, self.H, self.W), np.int64), np.empty(n, np.int32)
+        self._check(self._lib.fs_connected_components(self._h, n, _ptr(m), int(min_size_exclusive), _ptr(lab), _ptr(cnt)))
+        return (lab[0], int(cnt[0])) if single else (lab, cnt)
+
+    def crf_step(self, unary, Q, f1, f2, f3, val, want_potentials=False):
+        unary = _arr(unary, np.float32)
+        B, h, w, S = unary.shape
+        r = self.kernel_size
+        Q = _arr(Q, np.float32, (B, h + 2 * r, w + 2 * r, S))
+        f1 = _arr(f1, np.float32, (B, h + 2 * r, w + 2 * r, 3))
+        f2 = _arr(f2, np.float32, (B, h + 2 * r, w + 2 * r, 6))
+        f3 = _arr(f3, np.float32, (B, h + 2 * r, w + 2 * r, 5))
+        val = _arr(np.asarray(val, np.float32).reshape(-1, S)[0], np.float32)
+        out = np.empty((B, h, w, S), np.float32)
+        pot = np.empty((B, h, w, S), np.float32) if want_potentials else None
+        self._check(self._lib.fs_crf_step(self._h, B, h, w, S, _ptr(unary), _ptr(Q), _ptr(f1), _ptr(f2), _ptr(f3),
+                                          _ptr(val), _ptr(out), _ptr(pot)))
+        return (out, pot) if want_potentials else out
+
+    # -- fused path --------------------------------------------------------------
+    def find_surfaces_batch(self, depth, rgb):
+        """depth uint16 [n,H,W], rgb uint8 [n,H,W,3] -> dict of batched arrays with the
+        keys of the dict find_surfaces() returns (find_surfaces.py:503-532)."""
+        d, single = self._batch(depth)
+        c, _ = self._batch(rgb, (3,))
+        d, c = _arr(d, np.uint16), _arr(c, np.uint8)
+        n = d.shape[0]
+        out = {
+            "angles": np.empty((n, self.H, self.W, 2), np.float32),
+            "vectors": np.empty((n, self.H, self.W, 3), np.float32),
+            "points_3d": np.empty((n, self.H, self.W, 3), np.float32),
+            "patches": np.empty((n, self.H, self.W), np.int64),
+            "depth_edges": np.empty((n, self.H, self.W), np.int32),
+            "surfaces": np.empty((n, self.H, self.W), np.int64),
+        }
+        ns = np.empty(n, np.int32)
+        self._check(self._lib.fs_find_surfaces_batch(
+            self._h, n, _ptr(d), _ptr(c), _ptr(out["angles"]), _ptr(out["vectors"]), _ptr(out["points_3d"]),
+            _ptr(out["patches"]), _ptr(out["depth_edges"]), _ptr(out["surfaces"]), _ptr(ns)))
+        out["num_surfaces"] = ns
+        if single:
+            out = {k: v[0] for k, v in out.items()}
+            out["num_surfaces"] = int(out["num_surfaces"])
+        return out
+
+    def find_surfaces_batch_dev(self, n, d_depth, d_rgb, d_angles=None, d_vectors=None, d_points=None, d_patches=None,
+                                d_edges=None, d_surfaces=None):
+        """Device-pointer variant (integers or None); returns num_surfaces[n]."""
+        ns = np.empty(n, np.int32)
+        self._check(self._lib.fs_find_surfaces_batch_dev(self._h, n, d_depth, d_rgb, d_angles, d_vectors, d_points,
+                                                         d_patches, d_edges, d_surfaces, _ptr(ns)))
+        return ns
+
+    def apply_crf(self, labels, depth, rgb, angles):
+        lab, single = self._batch(labels)
+        d, _ = self._batch(depth)
+        c, _ = self._batch(rgb, (3,))
+        a, _ = self._batch(angles, (2,))
+        lab, d, c, a = _arr(lab, np.int64), _arr(d, np.uint16), _arr(c, np.uint8), _arr(a, np.float32)
+        out = np.empty_like(lab)
+        self._check(self._lib.fs_apply_crf(self._h, lab.shape[0], _ptr(lab), _ptr(d), _ptr(c), _ptr(a), _ptr(out)))
+        return out[0] if single else out

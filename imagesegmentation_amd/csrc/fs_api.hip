@@ -1,0 +1,558 @@
+// C ABI of libfs_hip.so (declared in include/fs_hip.h): context, device buffers
+// and the orchestration of the kernels in k_stencils.hip, k_cc.hip, k_crf.hip.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/fs_hip.h"
+#include "fs_common.h"
+
+using namespace fs;
+
+namespace {
+std::string g_create_error;
+
+enum { G_STENCIL = 0, G_CC = 1, G_SIM = 2, G_INIT = 3, G_ITER = 4, G_COUNT = 5 };
+
+struct EventPair { hipEvent_t a, b; };
+}  // namespace
+
+struct fs_ctx {
+    int device = 0, H = 0, W = 0, max_batch = 0;
+    int r = 7;
+    double view_x = 62.0 / 180 * M_PI, view_y = 48.6 / 180 * M_PI;   // config.py:6-7
+    bool have_params = false;
+    CrfParams params{};
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // tables
+    DevBuf tanx, tany, ax, ay, pos_terms;
+    // frame buffers, each sized for max_batch frames
+    DevBuf depth16, rgb8, depthf, smoothed, points, normals, raw, angles, curv, scores, mask, edges, patches64, patches32,
+        surfaces64;
+    DevBuf cc_parent, cc_count, cc_newid, cc_blocksum, cc_nlabels;
+    // CRF buffers (one frame in flight)
+    DevBuf simH, qa, qb, pot, unary, f1, f2, f3;
+    std::vector<int32_t> nlabels_host;
+
+    // timing
+    bool timing = false;
+    std::vector<EventPair> ev[G_COUNT];
+    size_t ev_used[G_COUNT] = {0, 0, 0, 0, 0};
+
+    int fail(hipError_t e, const char *what)
+    {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return -1;
+    }
+    int fail(const std::string &m)
+    {
+        err = m;
+        return -1;
+    }
+    size_t N() const { return (size_t)H * W; }
+};
+
+#define FS_HIP(expr)                                           \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return ctx->fail(e_, #expr);     \
+    } while (0)
+
+namespace {
+
+struct ScopedTimer {
+    fs_ctx *c;
+    int g;
+    EventPair *ep = nullptr;
+    ScopedTimer(fs_ctx *ctx, int group) : c(ctx), g(group)
+    {
+        if (!c->timing) return;
+        if (c->ev_used[g] == c->ev[g].size()) {
+            EventPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            c->ev[g].push_back(p);
+        }
+        ep = &c->ev[g][c->ev_used[g]++];
+        (void)hipEventRecord(ep->a, c->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (ep) (void)hipEventRecord(ep->b, c->stream);
+    }
+};
+
+int set_device(fs_ctx *ctx)
+{
+    FS_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// get_angle_arrays (image_processing_models_GPU.py:137-149) and the lateral pixel
+// size factors |tan[i-1] - tan[i+1]| of find_surfaces.py:237-238, on the host in
+// fp32 so that the tables are the same numbers a CPU evaluation would use.
+int build_tables(fs_ctx *ctx)
+{
+    const int H = ctx->H, W = ctx->W;
+    std::vector<float> tx(W), ty(H), ax(W, 0.0f), ay(H, 0.0f);
+    const float x_val = (float)(ctx->view_x / 2.0), y_val = (float)(ctx->view_y / 2.0);
+    const float dx = (float)(W / 2.0 - 0.5), dy = (float)(H / 2.0 - 0.5);
+    for (int c = 0; c < W; ++c) {
+        float v = ((float)c / dx) - 1.0f;
+        tx[c] = tanf(x_val * v);
+    }
+    for (int r = 0; r < H; ++r) {
+        float v = ((float)(H - 1 - r) / dy) - 1.0f;
+        ty[r] = tanf(y_val * v);
+    }
+    for (int c = 1; c < W - 1; ++c) ax[c] = fabsf(tx[c - 1] - tx[c + 1]);
+    for (int r = 1; r < H - 1; ++r) ay[r] = fabsf(ty[r - 1] - ty[r + 1]);
+    FS_HIP(ctx->tanx.ensure(W * sizeof(float)));
+    FS_HIP(ctx->tany.ensure(H * sizeof(float)));
+    FS_HIP(ctx->ax.ensure(W * sizeof(float)));
+    FS_HIP(ctx->ay.ensure(H * sizeof(float)));
+    FS_HIP(hipMemcpy(ctx->tanx.p, tx.data(), W * sizeof(float), hipMemcpyHostToDevice));
+    FS_HIP(hipMemcpy(ctx->tany.p, ty.data(), H * sizeof(float), hipMemcpyHostToDevice));
+    FS_HIP(hipMemcpy(ctx->ax.p, ax.data(), W * sizeof(float), hipMemcpyHostToDevice));
+    FS_HIP(hipMemcpy(ctx->ay.p, ay.data(), H * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Position terms of the three Gaussian kernels for every forward window offset:
+// theta^2 * ((dy/40)^2) + theta^2 * ((dx/40)^2), evaluated in the graph's order
+// (find_surfaces.py:343-350 with grid features, exponent mask 0 => divisor 1).
+int build_pos_terms(fs_ctx *ctx)
+{
+    const int r = ctx->r;
+    const size_t nh = crf_half_offsets(r);
+    std::vector<float> pt(3 * nh);
+    const float np_ = (float)(1.0 / 40.0);
+    for (int dy = 0; dy <= r; ++dy)
+        for (int dx = (dy == 0 ? 1 : -r); dx <= r; ++dx) {
+            const int oi = dy == 0 ? dx - 1 : r + (dy - 1) * (2 * r + 1) + (dx + r);
+            const float d0 = ((float)dy / 1.0f) * np_, d1 = ((float)dx / 1.0f) * np_;
+            pt[3 * oi + 0] = (d0 * d0) * ctx->params.t11 + (d1 * d1) * ctx->params.t11;
+            pt[3 * oi + 1] = (d0 * d0) * ctx->params.t21 + (d1 * d1) * ctx->params.t21;
+            pt[3 * oi + 2] = (d0 * d0) * ctx->params.t31 + (d1 * d1) * ctx->params.t31;
+        }
+    FS_HIP(ctx->pos_terms.ensure(pt.size() * sizeof(float)));
+    FS_HIP(hipMemcpy(ctx->pos_terms.p, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int check_batch(fs_ctx *ctx, int n)
+{
+    if (!ctx) return -1;
+    if (n < 1 || n > ctx->max_batch) return ctx->fail("batch size " + std::to_string(n) + " outside [1, max_batch=" + std::to_string(ctx->max_batch) + "]");
+    return set_device(ctx);
+}
+
+int ensure_frame_buffers(fs_ctx *ctx)
+{
+    const size_t n = ctx->max_batch, N = ctx->N();
+    FS_HIP(ctx->smoothed.ensure(n * N * 4));
+    FS_HIP(ctx->points.ensure(n * N * 12));
+    FS_HIP(ctx->normals.ensure(n * N * 12));
+    FS_HIP(ctx->raw.ensure(n * N * 8));
+    FS_HIP(ctx->angles.ensure(n * N * 8));
+    FS_HIP(ctx->curv.ensure(n * N));
+    FS_HIP(ctx->mask.ensure(n * N));
+    FS_HIP(ctx->edges.ensure(n * N * 4));
+    FS_HIP(ctx->patches64.ensure(n * N * 8));
+    FS_HIP(ctx->patches32.ensure(n * N * 4));
+    FS_HIP(ctx->surfaces64.ensure(n * N * 8));
+    FS_HIP(ctx->cc_parent.ensure(n * N * 4));
+    FS_HIP(ctx->cc_count.ensure(n * N * 4));
+    FS_HIP(ctx->cc_newid.ensure(n * N * 4));
+    FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
+    FS_HIP(ctx->cc_nlabels.ensure(n * 4));
+    return 0;
+}
+
+CcWork cc_work(fs_ctx *ctx)
+{
+    CcWork w;
+    w.parent = ctx->cc_parent.as<int32_t>();
+    w.count = ctx->cc_count.as<int32_t>();
+    w.newid = ctx->cc_newid.as<int32_t>();
+    w.blocksum = ctx->cc_blocksum.as<int32_t>();
+    w.nlabels = ctx->cc_nlabels.as<int32_t>();
+    return w;
+}
+
+// smoothed depth -> patches / edges (device), label counts to the host
+int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches64, int32_t *d_patches32, int32_t *d_edges,
+                float *d_scores, uint8_t *d_curv, bool read_counts)
+{
+    const int H = ctx->H, W = ctx->W;
+    const float threshold = (float)(0.007003343675404672 * 10.5);   // find_surfaces.py:229
+    {
+        ScopedTimer t(ctx, G_STENCIL);
+        launch_curvature_mask(d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), threshold, d_curv, d_scores, n, H, W, ctx->stream);
+        launch_majority_edges(d_curv, d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), 3.0f, ctx->mask.as<uint8_t>(), d_edges, n, H, W, ctx->stream);
+    }
+    {
+        ScopedTimer t(ctx, G_CC);
+        launch_connected_components(ctx->mask.as<uint8_t>(), cc_work(ctx), 20, d_patches64, d_patches32, n, H, W, ctx->stream);
+    }
+    FS_HIP(hipGetLastError());
+    if (read_counts) {
+        ctx->nlabels_host.resize(n);
+        FS_HIP(hipMemcpyAsync(ctx->nlabels_host.data(), ctx->cc_nlabels.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int ensure_crf_buffers(fs_ctx *ctx, size_t Npix, int S, bool want_pot)
+{
+    FS_HIP(ctx->simH.ensure(crf_half_offsets(ctx->r) * Npix * sizeof(float)));
+    FS_HIP(ctx->qa.ensure(Npix * S * sizeof(float)));
+    FS_HIP(ctx->qb.ensure(Npix * S * sizeof(float)));
+    if (want_pot) FS_HIP(ctx->pot.ensure(Npix * S * sizeof(float)));
+    return 0;
+}
+
+// CRF of one frame resident on the device: similarity planes, initial
+// probabilities from `labels32`, `iterations` mean-field updates, argmax.
+int run_crf_frame(fs_ctx *ctx, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
+                  const int32_t *d_labels32, int S, int iterations, int64_t *d_surfaces)
+{
+    const int H = ctx->H, W = ctx->W;
+    if (S > kMaxLabels) return ctx->fail("frame has " + std::to_string(S) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
+    if (ensure_crf_buffers(ctx, ctx->N(), S, false)) return -1;
+    {
+        ScopedTimer t(ctx, G_SIM);
+        launch_crf_sim(d_depth, d_rgb, d_angles, ctx->params, ctx->pos_terms.as<float>(), ctx->simH.as<float>(), H, W, ctx->r, ctx->stream);
+    }
+    {
+        ScopedTimer t(ctx, G_INIT);
+        launch_crf_init(d_labels32, ctx->qa.as<float>(), H, W, S, ctx->stream);
+    }
+    CrfFrame f{H, W, 0, 0, H, W, S, ctx->r};
+    float *qin = ctx->qa.as<float>(), *qout = ctx->qb.as<float>();
+    for (int it = 0; it < iterations; ++it) {
+        const bool last = it == iterations - 1;
+        ScopedTimer t(ctx, G_ITER);
+        hipError_t e = launch_crf_iter(ctx->simH.as<float>(), qin, last ? nullptr : qout, nullptr, nullptr, d_labels32, d_depth,
+                                       last ? d_surfaces : nullptr, f, ctx->params.weight, last ? CRF_LAST : 0, ctx->stream);
+        if (e != hipSuccess) return ctx->fail(e, "crf iteration launch (label count x window too large for LDS?)");
+        std::swap(qin, qout);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    if (height < 16 || width < 16 || max_batch < 1) {
+        g_create_error = "fs_create: need height, width >= 16 and max_batch >= 1";
+        return -1;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device < 0 || device >= count) {
+        g_create_error = std::string("fs_create: no such HIP device ") + std::to_string(device) + " (" + (e != hipSuccess ? hipGetErrorString(e) : "out of range") + ")";
+        return -1;
+    }
+    fs_ctx *ctx = new fs_ctx();
+    ctx->device = device;
+    ctx->H = height;
+    ctx->W = width;
+    ctx->max_batch = max_batch;
+    auto bail = [&](int) {
+        g_create_error = ctx->err;
+        fs_destroy(ctx);
+        return -1;
+    };
+    if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(0); }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
+    ctx->stream = ctx->own_stream;
+    if (build_tables(ctx)) return bail(0);
+    if (ensure_frame_buffers(ctx)) return bail(0);
+    *out = ctx;
+    return 0;
+}
+
+void fs_destroy(fs_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
+                      &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
+                      &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->cc_nlabels, &ctx->simH, &ctx->qa, &ctx->qb,
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &v : ctx->ev)
+        for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *fs_last_error(const fs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fs_set_view_angles(fs_ctx *ctx, double view_x, double view_y)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    ctx->view_x = view_x;
+    ctx->view_y = view_y;
+    return build_tables(ctx);
+}
+
+int fs_set_gauss_params(fs_ctx *ctx, const float p[13])
+{
+    if (!ctx || !p) return -1;
+    if (set_device(ctx)) return -1;
+    CrfParams &q = ctx->params;
+    q.w1 = p[0]; q.w2 = p[1]; q.w3 = p[2]; q.bias = p[3];
+    q.t11 = p[4] * p[4]; q.t21 = p[5] * p[5]; q.t31 = p[6] * p[6];
+    q.t12 = p[7] * p[7]; q.t22 = p[8] * p[8]; q.t32 = p[9] * p[9];
+    q.t23 = p[10] * p[10]; q.t33 = p[11] * p[11];
+    q.weight = p[12];
+    ctx->have_params = true;
+    return build_pos_terms(ctx);
+}
+
+int fs_set_kernel_size(fs_ctx *ctx, int kernel_size)
+{
+    if (!ctx) return -1;
+    if (kernel_size < 1 || kernel_size > kMaxRadius) return ctx->fail("kernel_size must be in [1, " + std::to_string(kMaxRadius) + "]");
+    if (set_device(ctx)) return -1;
+    ctx->r = kernel_size;
+    return ctx->have_params ? build_pos_terms(ctx) : 0;
+}
+
+int fs_set_stream(fs_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return -1;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return 0;
+}
+
+void *fs_stream(fs_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+int fs_set_timing(fs_ctx *ctx, int enable)
+{
+    if (!ctx) return -1;
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches)
+{
+    if (!ctx || group < 0 || group >= G_COUNT) return -1;
+    if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < ctx->ev_used[group]; ++i) {
+        float ms = 0.0f;
+        FS_HIP(hipEventElapsedTime(&ms, ctx->ev[group][i].a, ctx->ev[group][i].b));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)ctx->ev_used[group];
+    ctx->ev_used[group] = 0;
+    return 0;
+}
+
+int fs_smooth_depth(fs_ctx *ctx, int n, const float *depth, float *out)
+{
+    if (check_batch(ctx, n)) return -1;
+    const size_t bytes = (size_t)n * ctx->N() * 4;
+    FS_HIP(ctx->depthf.ensure(bytes));
+    FS_HIP(hipMemcpyAsync(ctx->depthf.p, depth, bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_smooth_depth_f32(ctx->depthf.as<float>(), ctx->smoothed.as<float>(), n, ctx->H, ctx->W, ctx->stream);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(out, ctx->smoothed.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_normals(fs_ctx *ctx, int n, const float *smoothed, float *angles, float *vectors, float *points, float *raw_angles)
+{
+    if (check_batch(ctx, n)) return -1;
+    const size_t px = (size_t)n * ctx->N();
+    FS_HIP(hipMemcpyAsync(ctx->smoothed.p, smoothed, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), ctx->points.as<float>(),
+                   ctx->normals.as<float>(), ctx->raw.as<float>(), n, ctx->H, ctx->W, ctx->stream);
+    launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), ctx->angles.as<float>(), n, ctx->H, ctx->W, ctx->stream);
+    FS_HIP(hipGetLastError());
+    if (angles) FS_HIP(hipMemcpyAsync(angles, ctx->angles.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (vectors) FS_HIP(hipMemcpyAsync(vectors, ctx->normals.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (points) FS_HIP(hipMemcpyAsync(points, ctx->points.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (raw_angles) FS_HIP(hipMemcpyAsync(raw_angles, ctx->raw.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_patches(fs_ctx *ctx, int n, const float *smoothed, int64_t *patches, int32_t *edges, float *curvature_scores,
+               uint8_t *curvature_mask)
+{
+    if (check_batch(ctx, n)) return -1;
+    const size_t px = (size_t)n * ctx->N();
+    FS_HIP(hipMemcpyAsync(ctx->smoothed.p, smoothed, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (curvature_scores) FS_HIP(ctx->scores.ensure(px * 4));
+    if (run_patches(ctx, n, ctx->smoothed.as<float>(), ctx->patches64.as<int64_t>(), nullptr, ctx->edges.as<int32_t>(),
+                    curvature_scores ? ctx->scores.as<float>() : nullptr, ctx->curv.as<uint8_t>(), false))
+        return -1;
+    if (patches) FS_HIP(hipMemcpyAsync(patches, ctx->patches64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (edges) FS_HIP(hipMemcpyAsync(edges, ctx->edges.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (curvature_scores) FS_HIP(hipMemcpyAsync(curvature_scores, ctx->scores.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (curvature_mask) FS_HIP(hipMemcpyAsync(curvature_mask, ctx->curv.p, px, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_size_exclusive, int64_t *labels, int32_t *num_labels)
+{
+    if (check_batch(ctx, n)) return -1;
+    const size_t px = (size_t)n * ctx->N();
+    FS_HIP(hipMemcpyAsync(ctx->mask.p, mask, px, hipMemcpyHostToDevice, ctx->stream));
+    launch_connected_components(ctx->mask.as<uint8_t>(), cc_work(ctx), min_size_exclusive, ctx->patches64.as<int64_t>(), nullptr, n, ctx->H, ctx->W, ctx->stream);
+    FS_HIP(hipGetLastError());
+    if (labels) FS_HIP(hipMemcpyAsync(labels, ctx->patches64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (num_labels) FS_HIP(hipMemcpyAsync(num_labels, ctx->cc_nlabels.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, const float *Q, const float *f1, const float *f2,
+                const float *f3, const float *val, float *out, float *potentials)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (!ctx->have_params) return ctx->fail("fs_crf_step: call fs_set_gauss_params first");
+    if (B < 1 || h < 1 || w < 1 || S < 2 || S > kMaxLabels) return ctx->fail("fs_crf_step: bad shape");
+    for (int l = 0; l < S; ++l)
+        if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step: val must be the one-hot of the last label");
+    const int r = ctx->r, hp = h + 2 * r, wp = w + 2 * r;
+    const size_t NP = (size_t)hp * wp, NO = (size_t)h * w;
+    FS_HIP(ctx->simH.ensure(crf_half_offsets(r) * NP * 4));
+    FS_HIP(ctx->qa.ensure(NP * S * 4));
+    FS_HIP(ctx->qb.ensure(NO * S * 4));
+    FS_HIP(ctx->unary.ensure(NO * S * 4));
+    FS_HIP(ctx->f1.ensure(NP * 3 * 4));
+    FS_HIP(ctx->f2.ensure(NP * 6 * 4));
+    FS_HIP(ctx->f3.ensure(NP * 5 * 4));
+    if (potentials) FS_HIP(ctx->pot.ensure(NO * S * 4));
+    CrfFrame f{hp, wp, r, r, h, w, S, r};
+    for (int b = 0; b < B; ++b) {
+        FS_HIP(hipMemcpyAsync(ctx->qa.p, Q + (size_t)b * NP * S, NP * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->unary.p, unary + (size_t)b * NO * S, NO * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->f1.p, f1 + (size_t)b * NP * 3, NP * 3 * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->f2.p, f2 + (size_t)b * NP * 6, NP * 6 * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->f3.p, f3 + (size_t)b * NP * 5, NP * 5 * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_crf_sim_explicit(ctx->f1.as<float>(), ctx->f2.as<float>(), ctx->f3.as<float>(), ctx->params, ctx->simH.as<float>(), hp, wp, r, ctx->stream);
+        hipError_t e = launch_crf_iter(ctx->simH.as<float>(), ctx->qa.as<float>(), ctx->qb.as<float>(),
+                                       potentials ? ctx->pot.as<float>() : nullptr, ctx->unary.as<float>(), nullptr, nullptr,
+                                       nullptr, f, ctx->params.weight, 0, ctx->stream);
+        if (e != hipSuccess) return ctx->fail(e, "fs_crf_step: launch (label count x window too large for LDS?)");
+        FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, ctx->qb.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (potentials) FS_HIP(hipMemcpyAsync(potentials + (size_t)b * NO * S, ctx->pot.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
+                               float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges, int64_t *d_surfaces,
+                               int32_t *num_surfaces)
+{
+    if (check_batch(ctx, n)) return -1;
+    if (!ctx->have_params) return ctx->fail("fs_find_surfaces: call fs_set_gauss_params first");
+    if (!d_depth || !d_rgb) return ctx->fail("fs_find_surfaces: depth and rgb are required");
+    const int H = ctx->H, W = ctx->W;
+    const size_t N = ctx->N();
+    float *angles = d_angles ? d_angles : ctx->angles.as<float>();
+    float *vectors = d_vectors ? d_vectors : ctx->normals.as<float>();
+    float *points = d_points ? d_points : ctx->points.as<float>();
+    int64_t *patches = d_patches ? d_patches : ctx->patches64.as<int64_t>();
+    int32_t *edges = d_edges ? d_edges : ctx->edges.as<int32_t>();
+    int64_t *surfaces = d_surfaces ? d_surfaces : ctx->surfaces64.as<int64_t>();
+    {
+        ScopedTimer t(ctx, G_STENCIL);
+        launch_smooth_depth_u16(d_depth, ctx->smoothed.as<float>(), n, H, W, ctx->stream);                 // find_surfaces.py:505
+        launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), points, vectors,
+                       ctx->raw.as<float>(), n, H, W, ctx->stream);                                            // :507
+        launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, n, H, W, ctx->stream);
+    }
+    if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
+                    ctx->curv.as<uint8_t>(), true))                                                            // :513
+        return -1;
+    for (int i = 0; i < n; ++i) {
+        const int ns = ctx->nlabels_host[i] + 1;                                                               // :514
+        if (num_surfaces) num_surfaces[i] = ns;
+        if (run_crf_frame(ctx, d_depth + i * N, d_rgb + i * N * 3, angles + i * N * 2, ctx->patches32.as<int32_t>() + i * N,
+                          ns + 1, 3, surfaces + i * N))                                                        // :515-532
+            return -1;
+    }
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint8_t *rgb, float *angles, float *vectors,
+                           float *points, int64_t *patches, int32_t *edges, int64_t *surfaces, int32_t *num_surfaces)
+{
+    if (check_batch(ctx, n)) return -1;
+    const size_t px = (size_t)n * ctx->N();
+    FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * ctx->N() * 2));
+    FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * ctx->N() * 3));
+    FS_HIP(hipMemcpyAsync(ctx->depth16.p, depth, px * 2, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, px * 3, hipMemcpyHostToDevice, ctx->stream));
+    if (fs_find_surfaces_batch_dev(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, num_surfaces))
+        return -1;
+    if (angles) FS_HIP(hipMemcpyAsync(angles, ctx->angles.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (vectors) FS_HIP(hipMemcpyAsync(vectors, ctx->normals.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (points) FS_HIP(hipMemcpyAsync(points, ctx->points.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (patches) FS_HIP(hipMemcpyAsync(patches, ctx->patches64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (edges) FS_HIP(hipMemcpyAsync(edges, ctx->edges.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (surfaces) FS_HIP(hipMemcpyAsync(surfaces, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *depth, const uint8_t *rgb, const float *angles,
+                 int64_t *out)
+{
+    if (check_batch(ctx, n)) return -1;
+    if (!ctx->have_params) return ctx->fail("fs_apply_crf: call fs_set_gauss_params first");
+    const size_t N = ctx->N(), px = (size_t)n * N;
+    // int64 labels -> int32 on the host (tiny), maximum per frame gives the channel count
+    std::vector<int32_t> lab32(px);
+    std::vector<int> S(n);
+    for (int i = 0; i < n; ++i) {
+        int64_t mx = 0;
+        for (size_t k = 0; k < N; ++k) {
+            const int64_t v = labels[i * N + k];
+            if (v < 0) return ctx->fail("fs_apply_crf: negative label");
+            lab32[i * N + k] = (int32_t)v;
+            if (v > mx) mx = v;
+        }
+        S[i] = (int)mx + 2;   // val = max + 1 surfaces, + the "unassigned" channel (post_processing.py:10-11)
+    }
+    FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
+    FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
+    FS_HIP(hipMemcpyAsync(ctx->depth16.p, depth, px * 2, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, px * 3, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->angles.p, angles, px * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < n; ++i)
+        if (run_crf_frame(ctx, ctx->depth16.as<uint16_t>() + i * N, ctx->rgb8.as<uint8_t>() + i * N * 3, ctx->angles.as<float>() + i * N * 2,
+                          ctx->patches32.as<int32_t>() + i * N, S[i], 1, ctx->surfaces64.as<int64_t>() + i * N))
+            return -1;
+    FS_HIP(hipMemcpyAsync(out, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

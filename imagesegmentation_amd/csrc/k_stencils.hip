@@ -1,0 +1,325 @@
+// LDS-tiled stencil kernels of the surface-detection front end (gfx950).
+//
+// Every kernel takes a batch of frames (blockIdx.z = frame), stages a tile plus
+// halo in LDS with zero fill outside the frame (the reference's SAME padding)
+// and evaluates one pixel per lane.  Arithmetic is fp32 with one rounding per
+// operation in the order the reference graph applies them; the file is compiled
+// with -ffp-contract=off and hipcc's default correctly-rounded fp32 divide/sqrt,
+// so the discrete outputs that depend on float comparisons (curvature mask,
+// depth edges) are bit-identical to an unfused CPU evaluation.
+#include "fs_common.h"
+
+namespace fs {
+
+namespace {
+
+constexpr int TW = 32;   // tile width  (lanes 0..31 of each half wave run along x: 128-byte rows)
+constexpr int TH = 8;    // tile height
+constexpr int NT = TW * TH;
+
+__device__ __forceinline__ float div_no_nan(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
+
+// Cooperative tile load with zero fill: tile[(TH+2R)][(TW+2R)] <- img[y0-R.., x0-R..]
+template <int R, typename T>
+__device__ __forceinline__ void load_tile(float (*tile)[TW + 2 * R + 1], const T *img, int H, int W, int x0, int y0)
+{
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R;
+    for (int i = threadIdx.x; i < LW * LH; i += NT) {
+        int ly = i / LW, lx = i - ly * LW;
+        int y = y0 + ly - R, x = x0 + lx - R;
+        float v = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = (float)img[(size_t)y * W + x];
+        tile[ly][lx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Depth smoothing: mean of the valid (>= 0.001) depths of the 7x7 window, 0 at
+// invalid centres.  Follows gaussian_filter_with_depth_factor_model_GPU
+// (image_processing_models_GPU.py:110-135) with sigma_1 = sigma_2 = 0.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void smooth_depth_kernel(const T *__restrict__ depth, float *__restrict__ out, int H, int W)
+{
+    constexpr int R = 3;
+    __shared__ float tile[TH + 2 * R][TW + 2 * R + 1];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    load_tile<R>(tile, depth + fo, H, W, x0, y0);
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    float sums = 0.0f, val = 0.0f;
+#pragma unroll
+    for (int wy = 0; wy <= 2 * R; ++wy)
+#pragma unroll
+        for (int wx = 0; wx <= 2 * R; ++wx) {
+            float d = tile[ty + wy][tx + wx];
+            float ind = d < 0.001f ? 0.0f : 1.0f;
+            sums = sums + ind;
+            val = val + ind * d;
+        }
+    float c = tile[ty + R][tx + R];
+    out[fo + (size_t)y * W + x] = div_no_nan(val, sums) * (c < 0.001f ? 0.0f : 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Back-projection, normals and raw angles: normals_model_GPU
+// (image_processing_models_GPU.py:151-178) + angle_calculator (:63-72).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(NT) void normals_kernel(const float *__restrict__ D, const float *__restrict__ tanx,
+                                                     const float *__restrict__ tany, float *__restrict__ points,
+                                                     float *__restrict__ normals, float *__restrict__ raw_angles,
+                                                     int H, int W)
+{
+    constexpr int R = 1;
+    __shared__ float tile[TH + 2 * R][TW + 2 * R + 1];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    load_tile<R>(tile, D + fo, H, W, x0, y0);
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    const float dc = tile[ty + 1][tx + 1];
+    const float txc = tanx[x], tyc = tany[y];
+    // neighbours' points; a neighbour outside the frame is the zero vector (tf.pad, :163-166)
+    const float du = tile[ty][tx + 1], dd = tile[ty + 2][tx + 1], dl = tile[ty + 1][tx], dr = tile[ty + 1][tx + 2];
+    const float tyu = y > 0 ? tany[y - 1] : 0.0f, tyd = y < H - 1 ? tany[y + 1] : 0.0f;
+    const float txl = x > 0 ? tanx[x - 1] : 0.0f, txr = x < W - 1 ? tanx[x + 1] : 0.0f;
+    float a[3], b[3], v[3];
+    a[0] = txc * du - txc * dd;   // sub_1 = P[y-1] - P[y+1]
+    a[1] = tyu * du - tyd * dd;
+    a[2] = du - dd;
+    b[0] = txr * dr - txl * dl;   // sub_2 = P[x+1] - P[x-1]
+    b[1] = tyc * dr - tyc * dl;
+    b[2] = dr - dl;
+    v[0] = a[1] * b[2] - a[2] * b[1];
+    v[1] = a[2] * b[0] - a[0] * b[2];
+    v[2] = a[0] * b[1] - a[1] * b[0];
+    const float cond = -(v[2] > 0.0f ? 1.0f : 0.0f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = 2.0f * (cond * v[i]) + v[i];
+    const float nrm = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    float n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) n[i] = div_no_nan(v[i], nrm);
+    const float v1[3] = {n[0] * 0.0f, n[1] * 1.0f, n[2] * 1.0f};
+    const float v2[3] = {n[0] * 1.0f, n[1] * 0.0f, n[2] * 1.0f};
+    const float n1 = sqrtf((v1[0] * v1[0] + v1[1] * v1[1]) + v1[2] * v1[2]);
+    const float n2 = sqrtf((v2[0] * v2[0] + v2[1] * v2[1]) + v2[2] * v2[2]);
+    const float a1 = acosf(fminf(fmaxf(div_no_nan(-v1[2], n1), -1.0f), 1.0f)) * signf(v1[1]);
+    const float a2 = acosf(fminf(fmaxf(div_no_nan(-v2[2], n2), -1.0f), 1.0f)) * (-signf(v2[0]));
+    const size_t i = fo + (size_t)y * W + x;
+    points[3 * i + 0] = txc * dc;
+    points[3 * i + 1] = tyc * dc;
+    points[3 * i + 2] = dc;
+    normals[3 * i + 0] = n[0];
+    normals[3 * i + 1] = n[1];
+    normals[3 * i + 2] = n[2];
+    raw_angles[2 * i + 0] = a1;
+    raw_angles[2 * i + 1] = a2;
+}
+
+// ---------------------------------------------------------------------------
+// Depth-gated 7x7 mean of the two angle channels:
+// uniform_filter_with_depth_cutoff + Depth_Cutoff
+// (image_processing_models_GPU.py:102-108, 86-88).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restrict__ raw, const float *__restrict__ D,
+                                                          float *__restrict__ angles, int H, int W)
+{
+    constexpr int R = 3;
+    constexpr int LW = TW + 2 * R, LH = TH + 2 * R;
+    __shared__ float td[LH][LW + 1];
+    __shared__ float ta0[LH][LW + 1];
+    __shared__ float ta1[LH][LW + 1];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < LW * LH; i += NT) {
+        int ly = i / LW, lx = i - ly * LW;
+        int y = y0 + ly - R, x = x0 + lx - R;
+        float d = 0.0f, a0 = 0.0f, a1 = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            size_t j = fo + (size_t)y * W + x;
+            d = D[j];
+            float2 a = reinterpret_cast<const float2 *>(raw)[j];
+            a0 = a.x;
+            a1 = a.y;
+        }
+        td[ly][lx] = d;
+        ta0[ly][lx] = a0;
+        ta1[ly][lx] = a1;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    const float dc = td[ty + R][tx + R];
+    float sums = 0.0f, v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+    for (int wy = 0; wy <= 2 * R; ++wy)
+#pragma unroll
+        for (int wx = 0; wx <= 2 * R; ++wx) {
+            float dj = td[ty + wy][tx + wx];
+            float m = fabsf(div_no_nan(dj - dc, dc)) > 0.3f ? 0.0f : 1.0f;
+            sums = sums + m;
+            v0 = v0 + m * ta0[ty + wy][tx + wx];
+            v1 = v1 + m * ta1[ty + wy][tx + wx];
+        }
+    float2 o;
+    o.x = div_no_nan(v0, sums);
+    o.y = div_no_nan(v1, sums);
+    reinterpret_cast<float2 *>(angles)[fo + (size_t)y * W + x] = o;
+}
+
+// ---------------------------------------------------------------------------
+// Curvature score + threshold (find_surfaces.py:232-262, depth = 4).
+// ax[c] = |tanx[c-1] - tanx[c+1]|, ay[r] = |tany[r-1] - tany[r+1]| are
+// precomputed on the host with the same fp32 operations.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restrict__ D, const float *__restrict__ ax,
+                                                            const float *__restrict__ ay, float threshold,
+                                                            uint8_t *__restrict__ mask, float *__restrict__ scores,
+                                                            int H, int W)
+{
+    constexpr int R = 4;
+    __shared__ float tile[TH + 2 * R][TW + 2 * R + 1];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    load_tile<R>(tile, D + fo, H, W, x0, y0);
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int c = x0 + tx, r = y0 + ty;
+    if (c >= W || r >= H) return;
+    const size_t i = fo + (size_t)r * W + c;
+    if (r < R || r >= H - R || c < R || c >= W - R) {   // zero border of tf.pad (:262)
+        mask[i] = 0;
+        if (scores) scores[i] = 0.0f;
+        return;
+    }
+    const float dc = tile[ty + R][tx + R];
+    const float dfx = (ax[c] * dc) * 0.5f;
+    const float dfy = (ay[r] * dc) * 0.5f;
+    float total = 0.0f;
+    const int d0s[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    const int d1s[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+            const float nx = dfx * (float)k, ny = dfy * (float)k;
+            const float nz = tile[ty + R - k * d0s[d]][tx + R - k * d1s[d]];
+            const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
+            const float dif1 = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+            const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
+            const float dif2 = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+            const float score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
+            cur = cur + score;
+            total = total + cur;
+            prevd = dif2;
+            px = nx; py = ny; pz = nz;
+        }
+    }
+    if (scores) scores[i] = total;
+    const uint8_t pix = total < threshold ? 1 : 0;
+    mask[i] = dc > 0.001f ? pix : 0;
+}
+
+// ---------------------------------------------------------------------------
+// 5x5 (>11) then 3x3 (>5) majority filters (find_surfaces.py:265-266), depth
+// edges (:269-278) and their product (:279), fused: the 5x5 result is kept in
+// LDS for the tile plus a one-pixel ring (zero outside the frame, as the second
+// extract_patches pads it).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void majority_edges_kernel(const uint8_t *__restrict__ curv, const float *__restrict__ D,
+                                                            const float *__restrict__ ax, const float *__restrict__ ay,
+                                                            float alpha, uint8_t *__restrict__ mask,
+                                                            int32_t *__restrict__ edges, int H, int W)
+{
+    constexpr int R = 3;
+    __shared__ float tm[TH + 2 * R][TW + 2 * R + 1];
+    __shared__ float td[TH + 2][TW + 2 + 1];
+    __shared__ int m5[TH + 2][TW + 2 + 1];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    load_tile<R>(tm, curv + fo, H, W, x0, y0);
+    load_tile<1>(td, D + fo, H, W, x0, y0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += NT) {
+        int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        int y = y0 + ly - 1, x = x0 + lx - 1;
+        int v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            float s = 0.0f;   // small integers: exact in fp32
+#pragma unroll
+            for (int wy = 0; wy < 5; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 5; ++wx) s += tm[ly + wy][lx + wx];
+            v = s > 11.0f ? 1 : 0;
+        }
+        m5[ly][lx] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int c = x0 + tx, r = y0 + ty;
+    if (c >= W || r >= H) return;
+    int s3 = 0;
+#pragma unroll
+    for (int wy = 0; wy < 3; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < 3; ++wx) s3 += m5[ty + wy][tx + wx];
+    const int pix = s3 > 5 ? 1 : 0;
+    int e = 0;
+    if (r >= 1 && r < H - 1 && c >= 1 && c < W - 1) {
+        const float dc = td[ty + 1][tx + 1];
+        const float fx = ((ax[c] * dc) * 0.5f) * alpha;
+        const float fy = ((ay[r] * dc) * 0.5f) * alpha;
+        e = 1;
+        if (fabsf(td[ty + 1][tx + 2] - dc) > fx) e = 0;
+        if (fabsf(td[ty + 1][tx] - dc) > fx) e = 0;
+        if (fabsf(td[ty][tx + 1] - dc) > fy) e = 0;
+        if (fabsf(td[ty + 2][tx + 1] - dc) > fy) e = 0;
+    }
+    const size_t i = fo + (size_t)r * W + c;
+    edges[i] = e;
+    mask[i] = (uint8_t)(e * pix);
+}
+
+inline dim3 tile_grid(int n, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, n); }
+
+}  // namespace
+
+void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(smooth_depth_kernel<uint16_t>, tile_grid(n, H, W), dim3(NT), 0, st, depth, out, H, W);
+}
+void launch_smooth_depth_f32(const float *depth, float *out, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(smooth_depth_kernel<float>, tile_grid(n, H, W), dim3(NT), 0, st, depth, out, H, W);
+}
+void launch_normals(const float *D, const float *tanx, const float *tany, float *points, float *normals,
+                    float *raw_angles, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(normals_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, tanx, tany, points, normals, raw_angles, H, W);
+}
+void launch_angle_filter(const float *raw_angles, const float *D, float *angles, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(angle_filter_kernel, tile_grid(n, H, W), dim3(NT), 0, st, raw_angles, D, angles, H, W);
+}
+void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
+                           float *scores, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, H, W);
+}
+void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
+                           uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(majority_edges_kernel, tile_grid(n, H, W), dim3(NT), 0, st, curv, D, ax, ay, alpha, mask, edges, H, W);
+}
+
+}  // namespace fs

@@ -1,0 +1,128 @@
+/*
+ * fs_hip.h -- C ABI of libfs_hip.so: MI355X (gfx950) implementation of the
+ * smooth-surface detection + CRF pixel-assignment stage ("find_surfaces").
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the reference repository).  All functions return 0 on success and a negative
+ * value on failure; fs_last_error() then holds a message.  A context is bound to
+ * one GPU and one stream and is not thread safe; use one context per GPU/thread.
+ * Host-pointer entry points copy in and out synchronously.  "_dev" entry points
+ * take device pointers, enqueue on the context's stream and return after the
+ * single host synchronisation the label count requires.
+ *
+ * Array layouts are the reference's: row-major [n][H][W][C] with the channel
+ * last, depth uint16 (0 = invalid), rgb uint8, patches/surfaces int64,
+ * depth_edges int32, everything else float32.
+ */
+#ifndef FS_HIP_H
+#define FS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_ctx fs_ctx;
+
+/* Creates a context for frames of height x width on GPU `device`, able to process
+ * up to max_batch frames per call.  Builds what get_GPU_models() builds once
+ * (find_surfaces.py:26-32): the viewing-angle tangent tables of get_angle_arrays()
+ * (image_processing_models_GPU.py:137-149, angles from config.py:6-7), and loads
+ * nothing from disk -- similarity parameters come through fs_set_gauss_params(). */
+int fs_create(fs_ctx **out, int device, int height, int width, int max_batch);
+void fs_destroy(fs_ctx *ctx);
+const char *fs_last_error(const fs_ctx *ctx);   /* ctx may be NULL: last creation error */
+
+/* Viewing angles in radians (config.py:6-7); defaults are 62 and 48.6 degrees. */
+int fs_set_view_angles(fs_ctx *ctx, double view_x, double view_y);
+
+/* The 13 values load_Gauss_parameters() returns (find_surfaces.py:221-226), in its
+ * order: w_1,w_2,w_3,bias,theta_1_1,theta_2_1,theta_3_1,theta_1_2,theta_2_2,
+ * theta_3_2,theta_2_3,theta_3_3,weight -- the argument list of conv_crf_Gauss()
+ * (find_surfaces.py:291).  Thetas are squared inside, as the graph does (:339-341). */
+int fs_set_gauss_params(fs_ctx *ctx, const float params[13]);
+
+/* CRF window radius, the kernel_size argument of conv_crf_Gauss / find_surfaces
+ * (find_surfaces.py:23, 291, 497); default 7, at most 15. */
+int fs_set_kernel_size(fs_ctx *ctx, int kernel_size);
+
+/* Use an existing HIP stream (a hipStream_t passed as void*) instead of the
+ * context's own; pass NULL to go back.  Returns the stream in use via fs_stream(). */
+int fs_set_stream(fs_ctx *ctx, void *hip_stream);
+void *fs_stream(fs_ctx *ctx);
+
+/* ---- stage operators: the four models of get_GPU_models() ------------------ */
+
+/* smoothing_model(depth, grid): gaussian_filter_with_depth_factor_model_GPU()
+ * (image_processing_models_GPU.py:110-135) with its defaults size=3, sigma=0.
+ * depth, out: float32 [n][H][W].  The grid input of the reference has no effect
+ * at sigma_2 = 0 and is not taken. */
+int fs_smooth_depth(fs_ctx *ctx, int n, const float *depth, float *out);
+
+/* normals_model_GPU() (image_processing_models_GPU.py:151-182): smoothed depth
+ * float32 [n][H][W] -> angles [n][H][W][2], vectors [n][H][W][3],
+ * points [n][H][W][3].  raw_angles (may be NULL) receives the unfiltered angles. */
+int fs_normals(fs_ctx *ctx, int n, const float *smoothed, float *angles, float *vectors, float *points,
+               float *raw_angles);
+
+/* find_surfaces_model_GPU() (find_surfaces.py:229-288) with its default
+ * arguments: smoothed depth -> patches int64 [n][H][W], depth edges int32.
+ * curvature_scores / curvature_mask (may be NULL) expose the intermediate of
+ * :232-262 (float32 / uint8 [n][H][W]) for testing. */
+int fs_patches(fs_ctx *ctx, int n, const float *smoothed, int64_t *patches, int32_t *edges,
+               float *curvature_scores, uint8_t *curvature_mask);
+
+/* Connected components alone: Components() (image_processing_models_GPU.py:74-76,
+ * tfa.image.connected_components) on a uint8 mask [n][H][W]; components with
+ * <= min_size_exclusive pixels are dropped before numbering (pass 0 to keep all). */
+int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_size_exclusive, int64_t *labels,
+                            int32_t *num_labels);
+
+/* conv_crf_Gauss(...).predict([unary, Q, f1, f2, f3, val], batch_size=1)
+ * (find_surfaces.py:291-367, 517-518): one mean-field update on B tiles.
+ *   unary [B][h][w][S], Q [B][h+2r][w+2r][S], f1 [B][h+2r][w+2r][3],
+ *   f2 [..][6], f3 [..][5], val [S] (must be the one-hot of the last label, the
+ *   only value the reference ever passes, find_surfaces.py:451-452);
+ *   out [B][h][w][S]; potentials (may be NULL) [B][h][w][S] receives
+ *   unary + weight * compatibility, the softmax argument. */
+int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, const float *Q, const float *f1,
+                const float *f2, const float *f3, const float *val, float *out, float *potentials);
+
+/* ---- fused path: find_surfaces() for a batch of frames ---------------------
+ * find_surfaces(models, image_data, "Gauss", kernel_size) (find_surfaces.py:497-
+ * 532) for n frames: depth uint16 [n][H][W], rgb uint8 [n][H][W][3] ->
+ * the arrays of the returned dict / of the out/{index} .npy files (:537-545):
+ * angles, vectors, points_3d, patches, depth_edges, surfaces ("Q.npy"),
+ * num_surfaces[n] = max(patches)+1.  Any output pointer may be NULL. */
+int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint8_t *rgb, float *angles,
+                           float *vectors, float *points, int64_t *patches, int32_t *edges, int64_t *surfaces,
+                           int32_t *num_surfaces);
+
+/* Same with all image arrays resident in device memory (num_surfaces stays a host
+ * array).  Work is enqueued on the context's stream; the call returns after the
+ * last kernel has been enqueued (it synchronises once internally to read the
+ * label counts). */
+int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
+                               float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges,
+                               int64_t *d_surfaces, int32_t *num_surfaces);
+
+/* post_processing.apply_CRF (post_processing.py:4-19): one mean-field pass with
+ * `labels` (int64 [n][H][W], e.g. final_surfaces) in the role of the patches, then
+ * argmax; depth uint16, rgb uint8, angles float32 [n][H][W][2] as saved by
+ * find_surfaces.  Host pointers.  out int64 [n][H][W]. */
+int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *depth, const uint8_t *rgb,
+                 const float *angles, int64_t *out);
+
+/* ---- instrumentation -------------------------------------------------------
+ * When enabled, HIP events are recorded on the context's stream around every
+ * kernel group; fs_get_timing() synchronises and returns accumulated device time
+ * (ms) and launch count per group, then resets.  Groups: 0 stencils,
+ * 1 connected components, 2 crf similarity, 3 crf init, 4 crf iteration. */
+int fs_set_timing(fs_ctx *ctx, int enable);
+int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS_HIP_H */
