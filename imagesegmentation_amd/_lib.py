@@ -136,8 +136,8 @@ class Context:
     def stream(self):
         return self._lib.fs_stream(self._h)
 
-    def set_timing(self, on):
-        self._check(self._lib.fs_set_timing(self._h, 1 if on else 0))
+    def set_timing(self, group_mask):
+        self._check(self._lib.fs_set_timing(self._h, int(group_mask)))
 
     def get_timing(self, group):
         ms, cnt = _d(0), _c.c_int64(0)

@@ -31,13 +31,14 @@ struct fs_ctx {
     // frame buffers, each sized for max_batch frames
     DevBuf depth16, rgb8, depthf, smoothed, points, normals, raw, angles, curv, scores, mask, edges, patches64, patches32,
         surfaces64;
-    DevBuf cc_parent, cc_count, cc_newid, cc_blocksum, cc_nlabels;
+    DevBuf cc_parent, cc_count, cc_newid, cc_blocksum;
     // CRF buffers (one frame in flight)
-    DevBuf simH, qa, qb, pot, unary, f1, f2, f3;
-    std::vector<int32_t> nlabels_host;
+    DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows;
+    DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
+    std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
 
     // timing
-    bool timing = false;
+    unsigned timing = 0;   // bit g set: record events around kernel group g
     std::vector<EventPair> ev[G_COUNT];
     size_t ev_used[G_COUNT] = {0, 0, 0, 0, 0};
 
@@ -68,7 +69,7 @@ struct ScopedTimer {
     EventPair *ep = nullptr;
     ScopedTimer(fs_ctx *ctx, int group) : c(ctx), g(group)
     {
-        if (!c->timing) return;
+        if (!(c->timing >> g & 1u)) return;
         if (c->ev_used[g] == c->ev[g].size()) {
             EventPair p;
             if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
@@ -166,7 +167,10 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_count.ensure(n * N * 4));
     FS_HIP(ctx->cc_newid.ensure(n * N * 4));
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
-    FS_HIP(ctx->cc_nlabels.ensure(n * 4));
+    FS_HIP(ctx->counts.ensure(2 * n * 4));
+    int tx, ty;
+    crf_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
+    FS_HIP(ctx->tile_recs.ensure(n * tx * ty * crf_tile_rec_ints() * 4));
     return 0;
 }
 
@@ -177,7 +181,7 @@ CcWork cc_work(fs_ctx *ctx)
     w.count = ctx->cc_count.as<int32_t>();
     w.newid = ctx->cc_newid.as<int32_t>();
     w.blocksum = ctx->cc_blocksum.as<int32_t>();
-    w.nlabels = ctx->cc_nlabels.as<int32_t>();
+    w.nlabels = ctx->counts.as<int32_t>();
     return w;
 }
 
@@ -198,33 +202,49 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
     }
     FS_HIP(hipGetLastError());
     if (read_counts) {
-        ctx->nlabels_host.resize(n);
-        FS_HIP(hipMemcpyAsync(ctx->nlabels_host.data(), ctx->cc_nlabels.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        // per-tile active patch labels for the CRF (needs only the patches), then one readback of
+        // label counts and per-frame maxima
+        int32_t *maxa = ctx->counts.as<int32_t>() + n;
+        FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
+        {
+            ScopedTimer t(ctx, G_INIT);
+            launch_crf_tile_active(d_patches32, n, H, W, ctx->r, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+        }
+        ctx->counts_host.resize(2 * n);
+        FS_HIP(hipMemcpyAsync(ctx->counts_host.data(), ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;
 }
 
-int ensure_crf_buffers(fs_ctx *ctx, size_t Npix, int S, bool want_pot)
+// similarity planes with zeroed slack on both sides; returns the pointer to plane 0
+int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, float **plane0)
 {
-    FS_HIP(ctx->simH.ensure(crf_half_offsets(ctx->r) * Npix * sizeof(float)));
-    FS_HIP(ctx->qa.ensure(Npix * S * sizeof(float)));
-    FS_HIP(ctx->qb.ensure(Npix * S * sizeof(float)));
-    if (want_pot) FS_HIP(ctx->pot.ensure(Npix * S * sizeof(float)));
+    const size_t slack = crf_sim_slack(Wimg, ctx->r);
+    const size_t floats = crf_half_offsets(ctx->r) * Npix + 2 * slack;
+    if (floats * sizeof(float) > ctx->simH.cap) {
+        FS_HIP(ctx->simH.ensure(floats * sizeof(float)));
+        FS_HIP(hipMemsetAsync(ctx->simH.p, 0, ctx->simH.cap, ctx->stream));
+    }
+    *plane0 = ctx->simH.as<float>() + slack;
     return 0;
 }
 
 // CRF of one frame resident on the device: similarity planes, initial
 // probabilities from `labels32`, `iterations` mean-field updates, argmax.
 int run_crf_frame(fs_ctx *ctx, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
-                  const int32_t *d_labels32, int S, int iterations, int64_t *d_surfaces)
+                  const int32_t *d_labels32, int S, int iterations, int64_t *d_surfaces, const int32_t *d_tile_recs,
+                  int max_active)
 {
     const int H = ctx->H, W = ctx->W;
     if (S > kMaxLabels) return ctx->fail("frame has " + std::to_string(S) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
-    if (ensure_crf_buffers(ctx, ctx->N(), S, false)) return -1;
+    float *sim0 = nullptr;
+    if (ensure_sim(ctx, ctx->N(), W, &sim0)) return -1;
+    FS_HIP(ctx->qa.ensure(ctx->N() * S * sizeof(float)));
+    FS_HIP(ctx->qb.ensure(ctx->N() * S * sizeof(float)));
     {
         ScopedTimer t(ctx, G_SIM);
-        launch_crf_sim(d_depth, d_rgb, d_angles, ctx->params, ctx->pos_terms.as<float>(), ctx->simH.as<float>(), H, W, ctx->r, ctx->stream);
+        launch_crf_sim(d_depth, d_rgb, d_angles, ctx->params, ctx->pos_terms.as<float>(), sim0, H, W, ctx->r, ctx->stream);
     }
     {
         ScopedTimer t(ctx, G_INIT);
@@ -235,9 +255,10 @@ int run_crf_frame(fs_ctx *ctx, const uint16_t *d_depth, const uint8_t *d_rgb, co
     for (int it = 0; it < iterations; ++it) {
         const bool last = it == iterations - 1;
         ScopedTimer t(ctx, G_ITER);
-        hipError_t e = launch_crf_iter(ctx->simH.as<float>(), qin, last ? nullptr : qout, nullptr, nullptr, d_labels32, d_depth,
-                                       last ? d_surfaces : nullptr, f, ctx->params.weight, last ? CRF_LAST : 0, ctx->stream);
-        if (e != hipSuccess) return ctx->fail(e, "crf iteration launch (label count x window too large for LDS?)");
+        hipError_t e = launch_crf_iter(sim0, qin, last ? nullptr : qout, nullptr, nullptr, d_labels32, d_depth,
+                                       last ? d_surfaces : nullptr, d_tile_recs, max_active + 3, f, ctx->params.weight,
+                                       last ? CRF_LAST : 0, ctx->stream);
+        if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
         std::swap(qin, qout);
     }
     return 0;
@@ -288,8 +309,8 @@ void fs_destroy(fs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
-                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->cc_nlabels, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3};
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->tile_recs, &ctx->simH, &ctx->qa, &ctx->qb,
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -328,6 +349,7 @@ int fs_set_kernel_size(fs_ctx *ctx, int kernel_size)
     if (kernel_size < 1 || kernel_size > kMaxRadius) return ctx->fail("kernel_size must be in [1, " + std::to_string(kMaxRadius) + "]");
     if (set_device(ctx)) return -1;
     ctx->r = kernel_size;
+    if (ensure_frame_buffers(ctx)) return -1;
     return ctx->have_params ? build_pos_terms(ctx) : 0;
 }
 
@@ -343,7 +365,7 @@ void *fs_stream(fs_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream
 int fs_set_timing(fs_ctx *ctx, int enable)
 {
     if (!ctx) return -1;
-    ctx->timing = enable != 0;
+    ctx->timing = (unsigned)enable;
     return 0;
 }
 
@@ -420,7 +442,7 @@ int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_siz
     launch_connected_components(ctx->mask.as<uint8_t>(), cc_work(ctx), min_size_exclusive, ctx->patches64.as<int64_t>(), nullptr, n, ctx->H, ctx->W, ctx->stream);
     FS_HIP(hipGetLastError());
     if (labels) FS_HIP(hipMemcpyAsync(labels, ctx->patches64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (num_labels) FS_HIP(hipMemcpyAsync(num_labels, ctx->cc_nlabels.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (num_labels) FS_HIP(hipMemcpyAsync(num_labels, ctx->counts.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -436,28 +458,37 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
         if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step: val must be the one-hot of the last label");
     const int r = ctx->r, hp = h + 2 * r, wp = w + 2 * r;
     const size_t NP = (size_t)hp * wp, NO = (size_t)h * w;
-    FS_HIP(ctx->simH.ensure(crf_half_offsets(r) * NP * 4));
+    float *sim0 = nullptr;
+    if (ensure_sim(ctx, NP, wp, &sim0)) return -1;
+    FS_HIP(ctx->rows.ensure(NP * S * 4));
     FS_HIP(ctx->qa.ensure(NP * S * 4));
     FS_HIP(ctx->qb.ensure(NO * S * 4));
     FS_HIP(ctx->unary.ensure(NO * S * 4));
+    FS_HIP(ctx->pot.ensure(NO * S * 4));
     FS_HIP(ctx->f1.ensure(NP * 3 * 4));
     FS_HIP(ctx->f2.ensure(NP * 6 * 4));
     FS_HIP(ctx->f3.ensure(NP * 5 * 4));
-    if (potentials) FS_HIP(ctx->pot.ensure(NO * S * 4));
     CrfFrame f{hp, wp, r, r, h, w, S, r};
+    float *rows = ctx->rows.as<float>();
     for (int b = 0; b < B; ++b) {
-        FS_HIP(hipMemcpyAsync(ctx->qa.p, Q + (size_t)b * NP * S, NP * S * 4, hipMemcpyHostToDevice, ctx->stream));
-        FS_HIP(hipMemcpyAsync(ctx->unary.p, unary + (size_t)b * NO * S, NO * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        // pixel-major host tensors -> label planes
+        FS_HIP(hipMemcpyAsync(rows, Q + (size_t)b * NP * S, NP * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_rows_to_planes(rows, ctx->qa.as<float>(), NP, S, ctx->stream);
+        FS_HIP(hipMemcpyAsync(rows, unary + (size_t)b * NO * S, NO * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_rows_to_planes(rows, ctx->unary.as<float>(), NO, S, ctx->stream);
         FS_HIP(hipMemcpyAsync(ctx->f1.p, f1 + (size_t)b * NP * 3, NP * 3 * 4, hipMemcpyHostToDevice, ctx->stream));
         FS_HIP(hipMemcpyAsync(ctx->f2.p, f2 + (size_t)b * NP * 6, NP * 6 * 4, hipMemcpyHostToDevice, ctx->stream));
         FS_HIP(hipMemcpyAsync(ctx->f3.p, f3 + (size_t)b * NP * 5, NP * 5 * 4, hipMemcpyHostToDevice, ctx->stream));
-        launch_crf_sim_explicit(ctx->f1.as<float>(), ctx->f2.as<float>(), ctx->f3.as<float>(), ctx->params, ctx->simH.as<float>(), hp, wp, r, ctx->stream);
-        hipError_t e = launch_crf_iter(ctx->simH.as<float>(), ctx->qa.as<float>(), ctx->qb.as<float>(),
-                                       potentials ? ctx->pot.as<float>() : nullptr, ctx->unary.as<float>(), nullptr, nullptr,
-                                       nullptr, f, ctx->params.weight, 0, ctx->stream);
-        if (e != hipSuccess) return ctx->fail(e, "fs_crf_step: launch (label count x window too large for LDS?)");
-        FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, ctx->qb.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (potentials) FS_HIP(hipMemcpyAsync(potentials + (size_t)b * NO * S, ctx->pot.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        launch_crf_sim_explicit(ctx->f1.as<float>(), ctx->f2.as<float>(), ctx->f3.as<float>(), ctx->params, sim0, hp, wp, r, ctx->stream);
+        hipError_t e = launch_crf_iter(sim0, ctx->qa.as<float>(), ctx->qb.as<float>(), potentials ? ctx->pot.as<float>() : nullptr,
+                                       ctx->unary.as<float>(), nullptr, nullptr, nullptr, nullptr, S, f, ctx->params.weight, 0, ctx->stream);
+        if (e != hipSuccess) return ctx->fail(e, "fs_crf_step: launch");
+        launch_planes_to_rows(ctx->qb.as<float>(), rows, NO, S, ctx->stream);
+        FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, rows, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (potentials) {
+            launch_planes_to_rows(ctx->pot.as<float>(), rows, NO, S, ctx->stream);
+            FS_HIP(hipMemcpyAsync(potentials + (size_t)b * NO * S, rows, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         FS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;
@@ -488,11 +519,14 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
                     ctx->curv.as<uint8_t>(), true))                                                            // :513
         return -1;
+    int tiles_x, tiles_y;
+    crf_tile_grid(H, W, ctx->r, &tiles_x, &tiles_y);
+    const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
     for (int i = 0; i < n; ++i) {
-        const int ns = ctx->nlabels_host[i] + 1;                                                               // :514
+        const int ns = ctx->counts_host[i] + 1;                                                                // :514
         if (num_surfaces) num_surfaces[i] = ns;
         if (run_crf_frame(ctx, d_depth + i * N, d_rgb + i * N * 3, angles + i * N * 2, ctx->patches32.as<int32_t>() + i * N,
-                          ns + 1, 3, surfaces + i * N))                                                        // :515-532
+                          ns + 1, 3, surfaces + i * N, ctx->tile_recs.as<int32_t>() + i * rec_stride, ctx->counts_host[n + i]))  // :515-532
             return -1;
     }
     FS_HIP(hipGetLastError());
@@ -546,9 +580,19 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, px * 3, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemcpyAsync(ctx->angles.p, angles, px * 8, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
+    int32_t *maxa = ctx->counts.as<int32_t>() + n;
+    FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
+    launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, ctx->r, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+    ctx->counts_host.resize(2 * n);
+    FS_HIP(hipMemcpyAsync(ctx->counts_host.data() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    int tiles_x, tiles_y;
+    crf_tile_grid(ctx->H, ctx->W, ctx->r, &tiles_x, &tiles_y);
+    const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
     for (int i = 0; i < n; ++i)
         if (run_crf_frame(ctx, ctx->depth16.as<uint16_t>() + i * N, ctx->rgb8.as<uint8_t>() + i * N * 3, ctx->angles.as<float>() + i * N * 2,
-                          ctx->patches32.as<int32_t>() + i * N, S[i], 1, ctx->surfaces64.as<int64_t>() + i * N))
+                          ctx->patches32.as<int32_t>() + i * N, S[i], 1, ctx->surfaces64.as<int64_t>() + i * N,
+                          ctx->tile_recs.as<int32_t>() + i * rec_stride, ctx->counts_host[n + i]))
             return -1;
     FS_HIP(hipMemcpyAsync(out, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));

@@ -67,15 +67,27 @@ struct CrfFrame {            // one image (or one padded tile treated as an imag
     int r;                   // window radius
 };
 size_t crf_half_offsets(int r);
+size_t crf_sim_slack(int W, int r);      // floats of zeroed slack before and after the similarity planes
+int crf_tile_height(int r);              // rows per tile of the per-tile active-label records
+size_t crf_tile_rec_ints();              // ints per record
+void crf_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
 void launch_crf_sim(const uint16_t *depth, const uint8_t *rgb, const float *angles, const CrfParams &p,
                     const float *pos_terms, float *simH, int H, int W, int r, hipStream_t st);
 void launch_crf_sim_explicit(const float *f1, const float *f2, const float *f3, const CrfParams &p, float *simH,
                              int Hi, int Wi, int r, hipStream_t st);
 void launch_crf_init(const int32_t *patches, float *Q, int H, int W, int S, hipStream_t st);
+void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st);
+void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hipStream_t st);
+// patch labels present within `grow` pixels of every tile, for n frames; max_active[n] must be zeroed
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int r, int grow, int32_t *recs,
+                            int32_t *max_active, hipStream_t st);
 // mode bits for launch_crf_iter
 enum { CRF_LAST = 1 };
+// Q / potentials / unary are label planes.  tile_recs == nullptr: every label is carried (operator-level API);
+// otherwise max_channels = largest per-tile channel count (max active + 3).
 hipError_t launch_crf_iter(const float *simH, const float *Qin, float *Qout, float *potentials,
                            const float *unary_explicit, const int32_t *patches, const uint16_t *depth_raw,
-                           int64_t *surfaces, const CrfFrame &f, float weight, int mode, hipStream_t st);
+                           int64_t *surfaces, const int32_t *tile_recs, int max_channels, const CrfFrame &f, float weight,
+                           int mode, hipStream_t st);
 
 }  // namespace fs

@@ -3,22 +3,33 @@
 // host glue around it (get_inputs / assemble_outputs / the per-pixel unary loop,
 // find_surfaces.py:437-495) and the argmax + fix-ups of find_surfaces.py:520-532.
 //
-// Structure
-//   crf_sim     the similarity sim(p, q) = w1 s1 + w2 s2 + w3 s3 + bias is
-//               symmetric in (p, q) and does not change between the three
-//               mean-field iterations, so it is evaluated once per frame for the
-//               "forward" half of the window (dy > 0, or dy == 0 and dx > 0) and
-//               kept as planes simH[offset][pixel]; the backward half is read
-//               from the neighbour's forward entry.  Features are staged in LDS.
-//   crf_init    initial probabilities from the patch labels.
-//   crf_iter    one mean-field update: message sum over the (2r+1)^2-1 window
-//               with the label distributions of the tile + halo staged in LDS,
-//               Potts compatibility, softmax, the invalid-depth overrides and,
-//               on the last iteration, the argmax.  One pixel per lane, all label
-//               channels of the pixel in registers.
-// Pixels outside the frame contribute nothing (their Q is 0), which is what the
-// reference's zero padding of Q does; the reference's 4x4 tiling is not
-// reproduced because a halo of r makes it numerically invisible.
+// Data layout
+//   Q          label planes Q[l][pixel] (the reference is pixel-major): a lane per
+//              pixel then reads and writes 256 contiguous bytes per wave for every
+//              label it touches.
+//   simH       sim(p, q) = w1 s1 + w2 s2 + w3 s3 + bias is symmetric in (p, q) and
+//              identical in all mean-field iterations, so it is evaluated once per
+//              frame for the "forward" half of the window (dy > 0, or dy == 0 and
+//              dx > 0) and kept as planes simH[offset][pixel]; the backward half is
+//              the neighbour's forward entry.  The buffer carries r*W + r zeroed
+//              floats of slack at both ends so that shifted reads never leave it.
+//
+// Label compaction (the step that makes the update cheap)
+//   A label l whose patch has no pixel within r * iterations of a tile has, at
+//   every pixel the tile's update reads or writes, the same unary (1) and the same
+//   probability as every other such label: they are exchangeable.  crf_tile_active
+//   lists, per tile, the patch labels present in the tile grown by that distance;
+//   the update then carries only {label 0, the listed labels, one representative
+//   of all other labels with its multiplicity, the "unassigned" label S-1} --
+//   typically 4-8 channels instead of S = 10..65 -- and expands the result back to
+//   S planes.  In exact arithmetic this is the same update; in fp32 it differs
+//   from a dense evaluation by summation order only.
+//
+// crf_iter: one block = 64 x (4*PY) pixels, one wave per row group, each lane PY
+// vertically adjacent pixels, so that a neighbour's channel vector read from LDS
+// is used by up to PY pixels and consecutive lanes read consecutive 16-byte
+// slots (no bank conflicts).  Q of the tile + halo is staged in LDS 8 channels at a
+// time; the similarity planes stream from L2 with 256-byte wave loads.
 #include "fs_common.h"
 
 namespace fs {
@@ -37,8 +48,10 @@ __host__ __device__ __forceinline__ int half_index(int dy, int dx, int r)
 // similarity planes, fused-path features: raw depth (u16), raw RGB (u8), smoothed
 // angles (f32 x2); position features are the pixel coordinates, so their terms
 // depend on the offset only and come from pos_terms[offset][3].
+// exp() is evaluated as exp2(x * log2 e) on the hardware unit: its absolute error
+// on a value in (0, 1] stays below 3e-8, the size of one fp32 rounding.
 // ---------------------------------------------------------------------------
-constexpr int STW = 32, STH = 8, SNT = STW * STH;
+constexpr int STW = 64, STH = 4, SNT = STW * STH;
 
 __global__ __launch_bounds__(SNT) void crf_sim_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ rgb,
                                                       const float *__restrict__ angles, CrfParams P,
@@ -80,12 +93,12 @@ __global__ __launch_bounds__(SNT) void crf_sim_kernel(const uint16_t *__restrict
                 const float dj = fd[ji];
                 const float d2 = div_no_nan(dj - dc, (dc + dj) / 2.0f) * nd;
                 const float dd = (d2 * d2);
-                const float e3 = ((fr[ji] - rc) / 1.0f) * nc, e4 = ((fg[ji] - gc) / 1.0f) * nc, e5 = ((fb[ji] - bc) / 1.0f) * nc;
-                const float g3 = ((fa0[ji] - a0c) / 1.0f) * na, g4 = ((fa1[ji] - a1c) / 1.0f) * na;
+                const float e3 = (fr[ji] - rc) * nc, e4 = (fg[ji] - gc) * nc, e5 = (fb[ji] - bc) * nc;
+                const float g3 = (fa0[ji] - a0c) * na, g4 = (fa1[ji] - a1c) * na;
                 const float *pt = pos_terms + 3 * oi;
-                const float s1 = expf(-(pt[0] + dd * P.t12));
-                const float s2 = expf(-((((pt[1] + dd * P.t22) + (e3 * e3) * P.t23) + (e4 * e4) * P.t23) + (e5 * e5) * P.t23));
-                const float s3 = expf(-(((pt[2] + dd * P.t32) + (g3 * g3) * P.t33) + (g4 * g4) * P.t33));
+                const float s1 = __expf(-(pt[0] + dd * P.t12));
+                const float s2 = __expf(-((((pt[1] + dd * P.t22) + (e3 * e3) * P.t23) + (e4 * e4) * P.t23) + (e5 * e5) * P.t23));
+                const float s3 = __expf(-(((pt[2] + dd * P.t32) + (g3 * g3) * P.t33) + (g4 * g4) * P.t33));
                 sim = ((P.w1 * s1 + P.w2 * s2) + P.w3 * s3) + P.bias;
             }
             simH[(size_t)oi * N + p] = sim;
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(256) void crf_sim_explicit_kernel(const float *__re
 // ---------------------------------------------------------------------------
 // initial probabilities, get_unary_potentials_and_initial_probabilities
 // (find_surfaces.py:456-477): double arithmetic, cast to float like Keras does.
+// Writes label planes Q[l][p].
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void crf_init_kernel(const int32_t *__restrict__ patches, float *__restrict__ Q, int N, int S)
 {
@@ -143,192 +157,341 @@ __global__ __launch_bounds__(256) void crf_init_kernel(const int32_t *__restrict
     if (p >= N) return;
     const int ns = S - 1;
     const int lab = patches[p];
-    float *q = Q + (size_t)p * S;
-    if (lab == 0) {
-        const float pv = (float)(1.0 / (double)ns);
-        q[0] = 0.0f;
-        for (int l = 1; l < S; ++l) q[l] = pv;
-    } else {
-        const float other = (float)(1.0 / (double)(ns - 1) * 0.1);
-        for (int l = 0; l < S; ++l) q[l] = other;
-        q[lab] = (float)0.9;
-        q[0] = 0.0f;
+    const float pv = (float)(1.0 / (double)ns);
+    const float other = (float)(1.0 / (double)(ns - 1) * 0.1);
+    for (int l = 0; l < S; ++l) {
+        float v;
+        if (l == 0) v = 0.0f;
+        else if (lab == 0) v = pv;
+        else v = l == lab ? (float)0.9 : other;
+        Q[(size_t)l * N + p] = v;
+    }
+}
+
+// pixel-major [P][S] <-> label planes [S][P] (operator-level API only)
+__global__ __launch_bounds__(256) void rows_to_planes_kernel(const float *__restrict__ rows, float *__restrict__ planes, int P, int S)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)P * S) return;
+    const int p = (int)(i / S), l = (int)(i - (size_t)p * S);
+    planes[(size_t)l * P + p] = rows[i];
+}
+__global__ __launch_bounds__(256) void planes_to_rows_kernel(const float *__restrict__ planes, float *__restrict__ rows, int P, int S)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)P * S) return;
+    const int p = (int)(i / S), l = (int)(i - (size_t)p * S);
+    rows[i] = planes[(size_t)l * P + p];
+}
+
+// ---------------------------------------------------------------------------
+// per-tile list of the patch labels present within `grow` pixels of the tile.
+// record (TILE_REC ints): [0] = count A, [4..7] = bit mask, [8..8+A) = labels
+// ascending.  max_active[frame] receives the largest A of the frame.
+// ---------------------------------------------------------------------------
+constexpr int ITW = 64;                       // tile width of the update kernel
+constexpr int TILE_REC = kMaxLabels + 8;
+
+__global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tile_h,
+                                                              int grow, int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
+{
+    __shared__ unsigned mask[4];
+    const int frame = blockIdx.z;
+    const int32_t *P = patches + (size_t)frame * H * W;
+    const int tiles_x = gridDim.x, tiles_y = gridDim.y;
+    int32_t *rec = recs + ((size_t)frame * tiles_x * tiles_y + (size_t)blockIdx.y * tiles_x + blockIdx.x) * TILE_REC;
+    if (threadIdx.x < 4) mask[threadIdx.x] = 0u;
+    __syncthreads();
+    const int xa = max(0, (int)blockIdx.x * ITW - grow), xb = min(W, (int)(blockIdx.x + 1) * ITW + grow);
+    const int ya = max(0, (int)blockIdx.y * tile_h - grow), yb = min(H, (int)(blockIdx.y + 1) * tile_h + grow);
+    const int rw = xb - xa;
+    const int total = rw * (yb - ya);
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int yy = i / rw, xx = i - yy * rw;
+        const int lab = P[(size_t)(ya + yy) * W + xa + xx];
+        if (lab > 0 && lab < kMaxLabels) {
+            const unsigned bit = 1u << (lab & 31);
+            if (!(mask[lab >> 5] & bit)) atomicOr(&mask[lab >> 5], bit);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int A = 0;
+        for (int w = 0; w < 4; ++w) {
+            unsigned m = mask[w];
+            rec[4 + w] = (int32_t)m;
+            while (m) {
+                const int b = __ffs(m) - 1;
+                rec[8 + A++] = w * 32 + b;
+                m &= m - 1;
+            }
+        }
+        rec[0] = A;
+        atomicMax(max_active + frame, A);
     }
 }
 
 // ---------------------------------------------------------------------------
 // one mean-field update
 // ---------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int padded_labels(int S)
-{
-    int sp = (S + 3) & ~3;          // float4 granules ...
-    if (((sp >> 2) & 1) == 0) sp += 4;   // ... an odd number of them per pixel spreads lanes over the LDS banks
-    return sp;
-}
+struct IterArgs {
+    const float *simH;          // plane 0 (the buffer has slack in front of it)
+    const float *Qin;           // planes [S][Hi*Wi]
+    float *Qout;                // planes [S][oh*ow] or null
+    float *potentials;          // planes [S][oh*ow] or null
+    const float *unary;         // explicit planes [S][oh*ow] or null (then synthesised from patches)
+    const int32_t *patches;     // [Hi*Wi] or null
+    const uint16_t *depth_raw;  // [Hi*Wi] or null: invalid-depth override
+    int64_t *surfaces;          // [oh*ow] or null: argmax output
+    const int32_t *tile_recs;   // per-tile active-label records or null (all labels listed)
+    int rec_rows, rec_tiles_x;  // tile height the records were built for, records per tile row
+    CrfFrame f;
+    float weight;
+    int last;
+};
 
-template <int LC, int TWc, int THc>
-__global__ __launch_bounds__(TWc *THc) void crf_iter_kernel(const float *__restrict__ simH, const float *__restrict__ Qin,
-                                                            float *__restrict__ Qout, float *__restrict__ potentials,
-                                                            const float *__restrict__ unary_explicit,
-                                                            const int32_t *__restrict__ patches,
-                                                            const uint16_t *__restrict__ depth_raw,
-                                                            int64_t *__restrict__ surfaces, CrfFrame f, float weight, int mode)
+template <int R, int PY, int NCH>
+__global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
 {
-    constexpr int NTc = TWc * THc;
-    extern __shared__ float4 lds4[];
-    float *qt = reinterpret_cast<float *>(lds4);
-    const int r = f.r, S = f.S, SP = padded_labels(S);
-    const int LW = TWc + 2 * r, LH = THc + 2 * r;
-    const int wx0 = blockIdx.x * TWc, wy0 = blockIdx.y * THc;   // tile origin in the output window
-    const int ix0 = f.ox + wx0, iy0 = f.oy + wy0;               // ... and in the image
-    // stage Q of tile + halo: [LH][LW][SP], zero outside the image and in the label padding
-    for (int i = threadIdx.x; i < LH * LW * SP; i += NTc) {
-        const int px = i / SP, l = i - px * SP;
-        const int ly = px / LW, lx = px - ly * LW;
-        const int gy = iy0 - r + ly, gx = ix0 - r + lx;
-        float v = 0.0f;
-        if (l < S && gy >= 0 && gy < f.Hi && gx >= 0 && gx < f.Wi) v = Qin[((size_t)gy * f.Wi + gx) * S + l];
-        qt[i] = v;
+    constexpr int CH = 8;                 // channels staged per pass
+    constexpr int TH = 4 * PY;            // tile height
+    extern __shared__ float4 lds4[];      // [2][LH][LW] float4: channel quads of the staged pass
+    __shared__ int s_list[TILE_REC];      // [0]=CE [1]=n_rest [2]=rep_pos [4..7]=listed mask (without rep) [8..] labels
+
+    const int r = R ? R : a.f.r, S = a.f.S;
+    const int LW = ITW + 2 * r, LH = TH + 2 * r;
+    const int tid = threadIdx.x, tx = tid & 63, wv = tid >> 6;
+    const int wx0 = blockIdx.x * ITW, wy0 = blockIdx.y * TH;          // tile origin in the output window
+    const int ix0 = a.f.ox + wx0, iy0 = a.f.oy + wy0;                  // ... and in the image
+    const int Wi = a.f.Wi, Hi = a.f.Hi;
+    const size_t Ni = (size_t)Hi * Wi, No = (size_t)a.f.oh * a.f.ow;
+
+    // ---- channel list of this tile ----
+    if (a.tile_recs) {
+        const int32_t *rec = a.tile_recs + ((size_t)(wy0 / a.rec_rows) * a.rec_tiles_x + blockIdx.x) * TILE_REC;
+        for (int t = tid; t < TILE_REC; t += 256) s_list[t] = rec[t];
+        __syncthreads();
+        if (tid == 0) {
+            // [0, active..., representative of the rest, S-1]
+            const int A = s_list[0];
+            unsigned m[4] = {(unsigned)s_list[4], (unsigned)s_list[5], (unsigned)s_list[6], (unsigned)s_list[7]};
+            for (int i = A - 1; i >= 0; --i) s_list[9 + i] = s_list[8 + i];
+            s_list[8] = 0;
+            int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
+            if (n_rest > 0) {
+                int rep = 1;
+                while (m[rep >> 5] >> (rep & 31) & 1u) ++rep;   // smallest unlisted label in [1, S-2]
+                rep_pos = ce;
+                s_list[8 + ce++] = rep;
+            }
+            s_list[8 + ce++] = S - 1;
+            m[0] |= 1u;
+            m[(S - 1) >> 5] |= 1u << ((S - 1) & 31);
+            s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
+            s_list[4] = (int)m[0]; s_list[5] = (int)m[1]; s_list[6] = (int)m[2]; s_list[7] = (int)m[3];
+        }
+    } else {
+        for (int t = tid; t < S; t += 256) s_list[8 + t] = t;
+        if (tid == 0) { s_list[0] = S; s_list[1] = 0; s_list[2] = -1; }
+        if (tid < 4) {
+            const int lo = tid * 32;
+            unsigned m = S >= lo + 32 ? 0xffffffffu : (S > lo ? (1u << (S - lo)) - 1u : 0u);
+            s_list[4 + tid] = (int)m;
+        }
     }
     __syncthreads();
-    const int tx = threadIdx.x % TWc, ty = threadIdx.x / TWc;
-    const int wx = wx0 + tx, wy = wy0 + ty;
-    if (wx >= f.ow || wy >= f.oh) return;
-    const int gx = ix0 + tx, gy = iy0 + ty;
-    const size_t N = (size_t)f.Hi * f.Wi, p = (size_t)gy * f.Wi + gx;
+    const int CE = s_list[0], n_rest = s_list[1], rep_pos = s_list[2];
 
-    float acc[LC];
+    // ---- per-lane pixels: column tx, rows wv*PY + i ----
+    const int wx = wx0 + tx;
+    const int gx = ix0 + tx;
+    const bool col_ok = wx < a.f.ow;
+    bool ok[PY], valid[PY];
+    unsigned p[PY];     // pixel index in the image (< 2^31)
+    size_t wi[PY];      // pixel index in the output window
+    bool any_work = false;
 #pragma unroll
-    for (int l = 0; l < LC; ++l) acc[l] = 0.0f;
+    for (int i = 0; i < PY; ++i) {
+        const int wy = wy0 + wv * PY + i;
+        ok[i] = col_ok && wy < a.f.oh;
+        const int gy = iy0 + wv * PY + i;
+        p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
+        wi[i] = ok[i] ? (size_t)wy * a.f.ow + wx : 0;
+        valid[i] = ok[i] && !(a.depth_raw && a.depth_raw[p[i]] == 0);   // overridden pixels need no message
+        any_work |= valid[i];
+    }
+    const bool wave_work = __ballot(any_work) != 0ull;
 
-    const float *qc = qt + ((ty + r) * LW + (tx + r)) * SP;
-    for (int dy = 0; dy <= r; ++dy) {
-        const bool fy = gy + dy < f.Hi, by = gy - dy >= 0;
-        for (int dx = (dy == 0 ? 1 : -r); dx <= r; ++dx) {
-            const int oi = half_index(dy, dx, r);
-            const bool fin = fy && gx + dx >= 0 && gx + dx < f.Wi;
-            const bool bin = by && gx - dx >= 0 && gx - dx < f.Wi;
-            const int doff = dy * f.Wi + dx;
-            const float sf = fin ? simH[(size_t)oi * N + p] : 0.0f;
-            const float sb = bin ? simH[(size_t)oi * N + p - doff] : 0.0f;
-            const float4 *qf = reinterpret_cast<const float4 *>(qc + (dy * LW + dx) * SP);
-            const float4 *qb = reinterpret_cast<const float4 *>(qc - (dy * LW + dx) * SP);
+    float acc[NCH][PY][CH];
 #pragma unroll
-            for (int l4 = 0; l4 < LC / 4; ++l4) {
-                if (l4 * 4 < SP) {
-                    const float4 a = qf[l4], b = qb[l4];
-                    acc[4 * l4 + 0] = fmaf(sf, a.x, acc[4 * l4 + 0]);
-                    acc[4 * l4 + 1] = fmaf(sf, a.y, acc[4 * l4 + 1]);
-                    acc[4 * l4 + 2] = fmaf(sf, a.z, acc[4 * l4 + 2]);
-                    acc[4 * l4 + 3] = fmaf(sf, a.w, acc[4 * l4 + 3]);
-                    acc[4 * l4 + 0] = fmaf(sb, b.x, acc[4 * l4 + 0]);
-                    acc[4 * l4 + 1] = fmaf(sb, b.y, acc[4 * l4 + 1]);
-                    acc[4 * l4 + 2] = fmaf(sb, b.z, acc[4 * l4 + 2]);
-                    acc[4 * l4 + 3] = fmaf(sb, b.w, acc[4 * l4 + 3]);
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < PY; ++i)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[c][i][k] = 0.0f;
+
+    const int plane4 = LH * LW;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch * CH < CE) {
+            if (ch > 0) __syncthreads();
+            // stage channels [ch*8, ch*8+8) of the tile + halo; rows by wave, columns by lane
+            int labs[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) labs[k] = ch * CH + k < CE ? s_list[8 + ch * CH + k] : -1;
+            for (int ly = wv; ly < LH; ly += 4) {
+                const int gy = iy0 - r + ly;
+                const bool rowin = gy >= 0 && gy < Hi;
+                for (int lx = tx; lx < LW; lx += 64) {
+                    const int gxx = ix0 - r + lx;
+                    const bool in = rowin && gxx >= 0 && gxx < Wi;
+                    const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+                    float v[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) v[k] = (in && labs[k] >= 0) ? a.Qin[(size_t)labs[k] * Ni + q] : 0.0f;
+                    lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
+                    lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __syncthreads();
+            if (wave_work) {
+                // neighbour rows jr = 0 .. PY+2r-1 (LDS row wv*PY + jr); pixel i sees it at dy = jr - r - i
+                for (int jr = 0; jr < PY + 2 * r; ++jr) {
+                    const float4 *row0 = lds4 + (wv * PY + jr) * LW + tx + r;
+                    const float4 *row1 = row0 + plane4;
+#pragma unroll
+                    for (int dx = -r; dx <= r; ++dx) {
+                        float s[PY];
+#pragma unroll
+                        for (int i = 0; i < PY; ++i) {
+                            const int dy = jr - r - i;
+                            s[i] = 0.0f;
+                            if (dy >= -r && dy <= r && !(dy == 0 && dx == 0)) {
+                                const bool fwd = dy > 0 || (dy == 0 && dx > 0);
+                                const int oi = fwd ? half_index(dy, dx, r) : half_index(-dy, -dx, r);
+                                const float *pl = a.simH + ((long)oi * (long)Ni + (fwd ? 0l : (long)dy * Wi + dx));
+                                s[i] = pl[p[i]];
+                            }
+                        }
+                        const float4 q0 = row0[dx], q1 = row1[dx];
+#pragma unroll
+                        for (int i = 0; i < PY; ++i) {
+                            acc[ch][i][0] = fmaf(s[i], q0.x, acc[ch][i][0]);
+                            acc[ch][i][1] = fmaf(s[i], q0.y, acc[ch][i][1]);
+                            acc[ch][i][2] = fmaf(s[i], q0.z, acc[ch][i][2]);
+                            acc[ch][i][3] = fmaf(s[i], q0.w, acc[ch][i][3]);
+                            acc[ch][i][4] = fmaf(s[i], q1.x, acc[ch][i][4]);
+                            acc[ch][i][5] = fmaf(s[i], q1.y, acc[ch][i][5]);
+                            acc[ch][i][6] = fmaf(s[i], q1.z, acc[ch][i][6]);
+                            acc[ch][i][7] = fmaf(s[i], q1.w, acc[ch][i][7]);
+                        }
+                    }
                 }
             }
         }
     }
 
-    // message of the constant "unassigned" evidence: 0.00005 * onehot(S-1)
-    // (find_surfaces.py:356-357, 451-452)
-    // compensated total so that compatibility[l] = total - msg[l] keeps full relative accuracy
-    float tot = 0.0f, comp_lo = 0.0f;
-#pragma unroll
-    for (int l = 0; l < LC; ++l) {
-        if (l < S) {
-            if (l == S - 1) acc[l] = acc[l] + 0.00005f;
-            const float t = tot + acc[l];
-            const float bp = t - tot;
-            comp_lo += (tot - (t - bp)) + (acc[l] - bp);
-            tot = t;
-        }
-    }
-    const size_t wi = (size_t)wy * f.ow + wx;   // index in the output window
-    const int lab = patches ? patches[p] : 0;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int l = 0; l < LC; ++l) {
-        if (l < S) {
-            const float comp = (tot - acc[l]) + comp_lo;   // Potts: sum of the other labels' messages
-            float un;
-            if (unary_explicit) un = unary_explicit[wi * S + l];
-            else un = l == 0 ? 10.0f : ((lab != 0 && l == lab) ? 0.0f : 1.0f);
-            const float add = un + weight * comp;
-            if (potentials) potentials[wi * S + l] = add;
-            acc[l] = -add;
-            mx = fmaxf(mx, acc[l]);
-        }
-    }
-    float den = 0.0f;
-#pragma unroll
-    for (int l = 0; l < LC; ++l) {
-        if (l < S) {
-            acc[l] = expf(acc[l] - mx);
-            den = den + acc[l];
-        }
-    }
-    const bool last = (mode & CRF_LAST) != 0;
-    const bool invalid = depth_raw && depth_raw[p] == 0;   // Q[depth == 0] = prob | 0, find_surfaces.py:520-530
+    // ---- Potts compatibility, softmax, overrides, expansion to S planes ----
     const float pv = (float)(1.0 / (double)(S - 1));
-    int best = 0;
-    float bestv = -1.0f;
 #pragma unroll
-    for (int l = 0; l < LC; ++l) {
-        if (l < S) {
-            float q = acc[l] / den;
-            if (invalid) q = last ? 0.0f : (l == 0 ? 0.0f : pv);
-            if (q > bestv) { bestv = q; best = l; }
-            if (Qout) Qout[wi * S + l] = q;
+    for (int i = 0; i < PY; ++i) {
+        if (!ok[i]) continue;
+        const bool invalid = a.depth_raw && !valid[i];
+        const int own = a.patches ? a.patches[p[i]] : 0;
+        float m[NCH * CH];
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
+        // evidence of the constant "unassigned" input: 0.00005 * onehot(S-1)   (find_surfaces.py:356-357, 451-452)
+        // total over all S labels (the representative counts n_rest times), compensated so that
+        // compatibility[l] = total - msg[l] keeps full relative accuracy
+        float tot = 0.0f, tot_lo = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) {
+            if (c < CE) {
+                if (c == CE - 1) m[c] = m[c] + 0.00005f;
+                const float term = c == rep_pos ? m[c] * (float)n_rest : m[c];
+                const float t = tot + term;
+                const float bp = t - tot;
+                tot_lo += (tot - (t - bp)) + (term - bp);
+                tot = t;
+            }
         }
+        float mx = -INFINITY, add_rep = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) {
+            if (c < CE) {
+                const int lab = s_list[8 + c];
+                const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
+                float un;
+                if (a.unary) un = a.unary[(size_t)lab * No + wi[i]];
+                else un = lab == 0 ? 10.0f : ((own != 0 && lab == own) ? 0.0f : 1.0f);   // :459-472
+                const float add = un + a.weight * comp;            // :361
+                if (a.potentials) a.potentials[(size_t)lab * No + wi[i]] = add;
+                if (c == rep_pos) add_rep = add;
+                m[c] = -add;
+                mx = fmaxf(mx, m[c]);
+            }
+        }
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) {
+            if (c < CE) {
+                m[c] = expf(m[c] - mx);                             // softmax(-add), :363
+                den = den + (c == rep_pos ? m[c] * (float)n_rest : m[c]);
+            }
+        }
+        float q_rep = 0.0f;
+        int best = 0;
+        float bestv = -1.0f;
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) {
+            if (c < CE) {
+                const int lab = s_list[8 + c];
+                float q = m[c] / den;
+                if (invalid) q = a.last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
+                if (c == rep_pos) q_rep = q;
+                else if (a.Qout) a.Qout[(size_t)lab * No + wi[i]] = q;
+                if (q > bestv || (q == bestv && lab < best)) { bestv = q; best = lab; }   // first maximum, :531
+            }
+        }
+        if (n_rest > 0 && (a.Qout || a.potentials)) {
+            // every unlisted label carries the representative's value
+            for (int l = 1; l < S - 1; ++l) {
+                if ((unsigned)s_list[4 + (l >> 5)] >> (l & 31) & 1u) continue;
+                if (a.Qout) a.Qout[(size_t)l * No + wi[i]] = q_rep;
+                if (a.potentials) a.potentials[(size_t)l * No + wi[i]] = add_rep;
+            }
+        }
+        if (a.surfaces) a.surfaces[wi[i]] = best == S - 1 ? 0 : best;          // :532
     }
-    if (surfaces) surfaces[wi] = (best == S - 1) ? 0 : best;   // find_surfaces.py:531-532
 }
 
-template <int LC, int TWc, int THc>
-hipError_t launch_iter_t(const float *simH, const float *Qin, float *Qout, float *potentials, const float *unary_explicit,
-                         const int32_t *patches, const uint16_t *depth_raw, int64_t *surfaces, const CrfFrame &f,
-                         float weight, int mode, size_t lds_bytes, hipStream_t st)
+template <int R, int PY, int NCH>
+hipError_t launch_iter_t(const IterArgs &a, size_t lds_bytes, hipStream_t st)
 {
     static bool attr_set = false;
-    auto kern = crf_iter_kernel<LC, TWc, THc>;
+    auto kern = crf_iter_kernel<R, PY, NCH>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((f.ow + TWc - 1) / TWc, (f.oh + THc - 1) / THc);
-    hipLaunchKernelGGL(kern, grid, dim3(TWc * THc), lds_bytes, st, simH, Qin, Qout, potentials, unary_explicit, patches,
-                       depth_raw, surfaces, f, weight, mode);
+    dim3 grid((a.f.ow + ITW - 1) / ITW, (a.f.oh + 4 * PY - 1) / (4 * PY));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
     return hipGetLastError();
-}
-
-template <int TWc, int THc>
-hipError_t launch_iter_lc(int LC, const float *simH, const float *Qin, float *Qout, float *potentials,
-                          const float *unary_explicit, const int32_t *patches, const uint16_t *depth_raw, int64_t *surfaces,
-                          const CrfFrame &f, float weight, int mode, size_t lds_bytes, hipStream_t st)
-{
-#define FS_CASE(L)                                                                                                   \
-    case L:                                                                                                          \
-        return launch_iter_t<L, TWc, THc>(simH, Qin, Qout, potentials, unary_explicit, patches, depth_raw, surfaces, \
-                                          f, weight, mode, lds_bytes, st);
-    switch (LC) {
-        FS_CASE(8)
-        FS_CASE(16)
-        FS_CASE(24)
-        FS_CASE(32)
-        FS_CASE(48)
-        FS_CASE(64)
-        FS_CASE(96)
-        FS_CASE(128)
-    }
-#undef FS_CASE
-    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
 size_t crf_half_offsets(int r) { return (size_t)r + (size_t)r * (2 * r + 1); }
+size_t crf_sim_slack(int W, int r) { return (size_t)r * W + r; }
+int crf_tile_height(int r) { return r <= 7 ? 16 : 8; }
+size_t crf_tile_rec_ints() { return TILE_REC; }
+void crf_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)
+{
+    *tiles_x = (W + ITW - 1) / ITW;
+    *tiles_y = (H + crf_tile_height(r) - 1) / crf_tile_height(r);
+}
 
 void launch_crf_sim(const uint16_t *depth, const uint8_t *rgb, const float *angles, const CrfParams &p,
                     const float *pos_terms, float *simH, int H, int W, int r, hipStream_t st)
@@ -351,24 +514,57 @@ void launch_crf_init(const int32_t *patches, float *Q, int H, int W, int S, hipS
     hipLaunchKernelGGL(crf_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, patches, Q, N, S);
 }
 
+void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st)
+{
+    hipLaunchKernelGGL(rows_to_planes_kernel, dim3((unsigned)((P * S + 255) / 256)), dim3(256), 0, st, rows, planes, (int)P, S);
+}
+void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hipStream_t st)
+{
+    hipLaunchKernelGGL(planes_to_rows_kernel, dim3((unsigned)((P * S + 255) / 256)), dim3(256), 0, st, planes, rows, (int)P, S);
+}
+
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int r, int grow, int32_t *recs, int32_t *max_active,
+                            hipStream_t st)
+{
+    int tx, ty;
+    crf_tile_grid(H, W, r, &tx, &ty);
+    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, crf_tile_height(r), grow, recs, max_active);
+}
+
 hipError_t launch_crf_iter(const float *simH, const float *Qin, float *Qout, float *potentials,
                            const float *unary_explicit, const int32_t *patches, const uint16_t *depth_raw,
-                           int64_t *surfaces, const CrfFrame &f, float weight, int mode, hipStream_t st)
+                           int64_t *surfaces, const int32_t *tile_recs, int max_channels, const CrfFrame &f, float weight,
+                           int mode, hipStream_t st)
 {
     if (f.S < 2 || f.S > kMaxLabels || f.r < 1 || f.r > kMaxRadius) return hipErrorInvalidValue;
-    static const int lcs[] = {8, 16, 24, 32, 48, 64, 96, 128};
-    int LC = 128;
-    for (int c : lcs)
-        if (c >= f.S) { LC = c; break; }
-    const int SP = padded_labels(f.S);
-    const size_t budget = 160 * 1024;
-    auto bytes = [&](int tw, int th) { return (size_t)(tw + 2 * f.r) * (th + 2 * f.r) * SP * sizeof(float); };
-    // largest tile whose Q stage fits twice into a CU's LDS, else the largest that fits once
-    if (bytes(16, 8) * 2 <= budget || (bytes(16, 8) <= budget && bytes(8, 8) * 2 > budget))
-        return launch_iter_lc<16, 8>(LC, simH, Qin, Qout, potentials, unary_explicit, patches, depth_raw, surfaces, f, weight, mode, bytes(16, 8), st);
-    if (bytes(8, 8) <= budget)
-        return launch_iter_lc<8, 8>(LC, simH, Qin, Qout, potentials, unary_explicit, patches, depth_raw, surfaces, f, weight, mode, bytes(8, 8), st);
-    return hipErrorInvalidValue;   // label count x window too large for the LDS-staged kernel
+    int tiles_x, tiles_y;
+    crf_tile_grid(f.oh, f.ow, f.r, &tiles_x, &tiles_y);
+    IterArgs a{simH, Qin, Qout, potentials, unary_explicit, patches, depth_raw, surfaces, tile_recs,
+               crf_tile_height(f.r), tiles_x, f, weight, (mode & CRF_LAST) ? 1 : 0};
+    const int ce = max_channels < f.S ? max_channels : f.S;
+    const int nch = (ce + 7) / 8;
+    auto lds = [&](int py) { return (size_t)2 * (ITW + 2 * f.r) * (4 * py + 2 * f.r) * sizeof(float4); };
+    // accumulators are NCH x PY x 8 registers per lane: fewer rows per lane when many channels are live
+    if (f.r == 7 && nch <= 4) {
+        switch (nch) {
+        case 1: return launch_iter_t<7, 4, 1>(a, lds(4), st);
+        case 2: return launch_iter_t<7, 4, 2>(a, lds(4), st);
+        case 3: return launch_iter_t<7, 4, 3>(a, lds(4), st);
+        default: return launch_iter_t<7, 4, 4>(a, lds(4), st);
+        }
+    }
+    if (f.r <= 7 && nch <= 4) {
+        if (nch == 1) return launch_iter_t<0, 4, 1>(a, lds(4), st);
+        if (nch == 2) return launch_iter_t<0, 4, 2>(a, lds(4), st);
+        return launch_iter_t<0, 4, 4>(a, lds(4), st);
+    }
+    if (nch <= 8) {
+        if (nch == 1) return launch_iter_t<0, 2, 1>(a, lds(2), st);
+        if (nch == 2) return launch_iter_t<0, 2, 2>(a, lds(2), st);
+        if (nch <= 4) return launch_iter_t<0, 2, 4>(a, lds(2), st);
+        return launch_iter_t<0, 2, 8>(a, lds(2), st);
+    }
+    return launch_iter_t<0, 1, 16>(a, lds(1), st);
 }
 
 }  // namespace fs

@@ -115,11 +115,12 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
                  const float *angles, int64_t *out);
 
 /* ---- instrumentation -------------------------------------------------------
- * When enabled, HIP events are recorded on the context's stream around every
- * kernel group; fs_get_timing() synchronises and returns accumulated device time
- * (ms) and launch count per group, then resets.  Groups: 0 stencils,
- * 1 connected components, 2 crf similarity, 3 crf init, 4 crf iteration. */
-int fs_set_timing(fs_ctx *ctx, int enable);
+ * group_mask bit g set: HIP events are recorded on the context's stream around
+ * every launch of kernel group g; fs_get_timing() synchronises and returns the
+ * accumulated device time (ms) and launch count of a group, then resets it.
+ * Groups: 0 stencils, 1 connected components, 2 crf similarity, 3 crf init,
+ * 4 crf iteration (one launch = one mean-field update of one frame). */
+int fs_set_timing(fs_ctx *ctx, int group_mask);
 int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
