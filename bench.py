@@ -151,6 +151,7 @@ def main():
         }
         if not args.no_kernel_timing:
             ms, launches = ctx.get_timing(ITER)
+            # (each timed interval is one mean-field update of a group of up to 16 frames)
             # algorithmic bytes of one mean-field update of one frame: 24 B features + 4 B patch
             # label + 4S read Q + 4S write Q per pixel; the last update writes an int64 label
             # instead of Q.  Three updates per frame.
@@ -159,7 +160,7 @@ def main():
             achieved = total_bytes / (ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "crf_iter_kernel (mean-field update)", "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": int(launches),
+                               "avg_us_per_frame_update": 1e3 * ms / (3 * n * args.steps), "timed_intervals": int(launches),
                                "share_of_step_time": ms * 1e-3 / dt}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(depth, rgb)

@@ -1,8 +1,8 @@
 // C ABI of libfs_hip.so (declared in include/fs_hip.h): context, device buffers
 // and the orchestration of the kernels in k_stencils.hip, k_cc.hip, k_crf.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 
 #include "../../include/fs_hip.h"
 #include "fs_common.h"
@@ -33,7 +33,8 @@ struct fs_ctx {
         surfaces64;
     DevBuf cc_parent, cc_count, cc_newid, cc_blocksum;
     // CRF buffers (one frame in flight)
-    DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows;
+    DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs;
+    std::vector<CrfFrameDesc> descs_host;
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
 
@@ -169,7 +170,7 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
     FS_HIP(ctx->counts.ensure(2 * n * 4));
     int tx, ty;
-    crf_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
+    crf_tile_grid(ctx->H, ctx->W, &tx, &ty);
     FS_HIP(ctx->tile_recs.ensure(n * tx * ty * crf_tile_rec_ints() * 4));
     return 0;
 }
@@ -208,7 +209,7 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
         FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
         {
             ScopedTimer t(ctx, G_INIT);
-            launch_crf_tile_active(d_patches32, n, H, W, ctx->r, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+            launch_crf_tile_active(d_patches32, n, H, W, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
         }
         ctx->counts_host.resize(2 * n);
         FS_HIP(hipMemcpyAsync(ctx->counts_host.data(), ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -217,11 +218,13 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
     return 0;
 }
 
-// similarity planes with zeroed slack on both sides; returns the pointer to plane 0
-int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, float **plane0)
+// Similarity planes for `frames` frames of Npix pixels: [slack | planes*Npix | slack | planes*Npix | slack ...],
+// slack zeroed once and never written.  Returns plane 0 of frame 0 and the frame stride (floats).
+int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, int frames, float **plane0, size_t *stride)
 {
     const size_t slack = crf_sim_slack(Wimg, ctx->r);
-    const size_t floats = crf_half_offsets(ctx->r) * Npix + 2 * slack;
+    *stride = crf_half_offsets(ctx->r) * Npix + slack;
+    const size_t floats = slack + (size_t)frames * *stride;
     if (floats * sizeof(float) > ctx->simH.cap) {
         FS_HIP(ctx->simH.ensure(floats * sizeof(float)));
         FS_HIP(hipMemsetAsync(ctx->simH.p, 0, ctx->simH.cap, ctx->stream));
@@ -230,36 +233,102 @@ int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, float **plane0)
     return 0;
 }
 
-// CRF of one frame resident on the device: similarity planes, initial
-// probabilities from `labels32`, `iterations` mean-field updates, argmax.
-int run_crf_frame(fs_ctx *ctx, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
-                  const int32_t *d_labels32, int S, int iterations, int64_t *d_surfaces, const int32_t *d_tile_recs,
-                  int max_active)
+constexpr int kCrfGroup = 16;   // frames whose similarity planes are resident at a time
+
+// CRF of n frames resident on the device: similarity planes, initial probabilities from
+// `labels32`, `iterations` mean-field updates, argmax.  S[i] label channels and max_active[i]
+// listed labels per tile (host arrays).  Frames are processed in groups; inside a group all
+// frames of one kernel variant (channel class) share a launch.
+int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
+                  const int32_t *d_labels32, const int *S, const int *max_active, int iterations, int64_t *d_surfaces)
 {
     const int H = ctx->H, W = ctx->W;
-    if (S > kMaxLabels) return ctx->fail("frame has " + std::to_string(S) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
+    const size_t N = ctx->N();
+    int tiles_x, tiles_y;
+    crf_tile_grid(H, W, &tiles_x, &tiles_y);
+    const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
+    for (int i = 0; i < n; ++i)
+        if (S[i] > kMaxLabels) return ctx->fail("frame has " + std::to_string(S[i]) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
+    const int G = n < kCrfGroup ? n : kCrfGroup;
     float *sim0 = nullptr;
-    if (ensure_sim(ctx, ctx->N(), W, &sim0)) return -1;
-    FS_HIP(ctx->qa.ensure(ctx->N() * S * sizeof(float)));
-    FS_HIP(ctx->qb.ensure(ctx->N() * S * sizeof(float)));
-    {
-        ScopedTimer t(ctx, G_SIM);
-        launch_crf_sim(d_depth, d_rgb, d_angles, ctx->params, ctx->pos_terms.as<float>(), sim0, H, W, ctx->r, ctx->stream);
+    size_t sim_stride = 0;
+    if (ensure_sim(ctx, N, W, G, &sim0, &sim_stride)) return -1;
+    size_t qmax = 0;
+    for (int g0 = 0; g0 < n; g0 += G) {
+        size_t q = 0;
+        for (int i = g0; i < n && i < g0 + G; ++i) q += (size_t)S[i] * N;
+        if (q > qmax) qmax = q;
     }
-    {
-        ScopedTimer t(ctx, G_INIT);
-        launch_crf_init(d_labels32, ctx->qa.as<float>(), H, W, S, ctx->stream);
+    FS_HIP(ctx->qa.ensure(qmax * sizeof(float)));
+    FS_HIP(ctx->qb.ensure(qmax * sizeof(float)));
+
+    // descriptors: [group][iteration][frames of the group ordered by channel class]
+    std::vector<CrfFrameDesc> &dh = ctx->descs_host;
+    dh.assign((size_t)n * iterations, CrfFrameDesc{});
+    struct Launch { size_t first; int count, cls; };
+    std::vector<std::vector<Launch>> launches(((size_t)n + G - 1) / G * iterations);
+    for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
+        const int gn = (n - g0) < G ? (n - g0) : G;
+        std::vector<int> order(gn), cls(gn);
+        std::vector<size_t> qoff(gn);
+        size_t q = 0;
+        for (int k = 0; k < gn; ++k) {
+            order[k] = k;
+            int ce = max_active[g0 + k] + 3;
+            if (ce > S[g0 + k]) ce = S[g0 + k];
+            cls[k] = crf_channel_class(ce);
+            qoff[k] = q;
+            q += (size_t)S[g0 + k] * N;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a] < cls[b]; });
+        for (int it = 0; it < iterations; ++it) {
+            const bool last = it == iterations - 1;
+            float *qin = (it & 1) ? ctx->qb.as<float>() : ctx->qa.as<float>();
+            float *qout = (it & 1) ? ctx->qa.as<float>() : ctx->qb.as<float>();
+            const size_t base = (size_t)g0 * iterations + (size_t)it * gn;
+            for (int k = 0; k < gn; ++k) {
+                const int f = order[k], fi = g0 + f;
+                CrfFrameDesc &d = dh[base + k];
+                d.sim0 = sim0 + (size_t)f * sim_stride;
+                d.Qin = qin + qoff[f];
+                d.Qout = last ? nullptr : qout + qoff[f];
+                d.potentials = nullptr;
+                d.unary = nullptr;
+                d.patches = d_labels32 + (size_t)fi * N;
+                d.depth_raw = d_depth + (size_t)fi * N;
+                d.surfaces = last ? d_surfaces + (size_t)fi * N : nullptr;
+                d.tile_recs = ctx->tile_recs.as<int32_t>() + (size_t)fi * rec_stride;
+                d.S = S[fi];
+                if (k == 0 || cls[order[k]] != cls[order[k - 1]])
+                    launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f]});
+                else
+                    launches[(size_t)gi * iterations + it].back().count++;
+            }
+        }
     }
-    CrfFrame f{H, W, 0, 0, H, W, S, ctx->r};
-    float *qin = ctx->qa.as<float>(), *qout = ctx->qb.as<float>();
-    for (int it = 0; it < iterations; ++it) {
-        const bool last = it == iterations - 1;
-        ScopedTimer t(ctx, G_ITER);
-        hipError_t e = launch_crf_iter(sim0, qin, last ? nullptr : qout, nullptr, nullptr, d_labels32, d_depth,
-                                       last ? d_surfaces : nullptr, d_tile_recs, max_active + 3, f, ctx->params.weight,
-                                       last ? CRF_LAST : 0, ctx->stream);
-        if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
-        std::swap(qin, qout);
+    FS_HIP(ctx->descs.ensure(dh.size() * sizeof(CrfFrameDesc)));
+    FS_HIP(hipMemcpyAsync(ctx->descs.p, dh.data(), dh.size() * sizeof(CrfFrameDesc), hipMemcpyHostToDevice, ctx->stream));
+    const CrfFrameDesc *dd = ctx->descs.as<CrfFrameDesc>();
+    const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
+    for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
+        const int gn = (n - g0) < G ? (n - g0) : G;
+        {
+            ScopedTimer t(ctx, G_SIM);
+            launch_crf_sim(d_depth + (size_t)g0 * N, d_rgb + (size_t)g0 * N * 3, d_angles + (size_t)g0 * N * 2, ctx->params,
+                           ctx->pos_terms.as<float>(), sim0, sim_stride, gn, H, W, ctx->r, ctx->stream);
+        }
+        {
+            ScopedTimer t(ctx, G_INIT);
+            launch_crf_init(dd + (size_t)g0 * iterations, gn, H, W, ctx->stream);
+        }
+        for (int it = 0; it < iterations; ++it) {
+            ScopedTimer t(ctx, G_ITER);
+            for (const Launch &l : launches[(size_t)gi * iterations + it]) {
+                hipError_t e = launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight,
+                                               it == iterations - 1 ? CRF_LAST : 0, ctx->stream);
+                if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
+            }
+        }
     }
     return 0;
 }
@@ -310,7 +379,7 @@ void fs_destroy(fs_ctx *ctx)
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->tile_recs, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows};
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -459,7 +528,8 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
     const int r = ctx->r, hp = h + 2 * r, wp = w + 2 * r;
     const size_t NP = (size_t)hp * wp, NO = (size_t)h * w;
     float *sim0 = nullptr;
-    if (ensure_sim(ctx, NP, wp, &sim0)) return -1;
+    size_t sim_stride = 0;
+    if (ensure_sim(ctx, NP, wp, 1, &sim0, &sim_stride)) return -1;
     FS_HIP(ctx->rows.ensure(NP * S * 4));
     FS_HIP(ctx->qa.ensure(NP * S * 4));
     FS_HIP(ctx->qb.ensure(NO * S * 4));
@@ -468,7 +538,17 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
     FS_HIP(ctx->f1.ensure(NP * 3 * 4));
     FS_HIP(ctx->f2.ensure(NP * 6 * 4));
     FS_HIP(ctx->f3.ensure(NP * 5 * 4));
-    CrfFrame f{hp, wp, r, r, h, w, S, r};
+    FS_HIP(ctx->descs.ensure(sizeof(CrfFrameDesc)));
+    CrfFrameDesc d{};
+    d.sim0 = sim0;
+    d.Qin = ctx->qa.as<float>();
+    d.Qout = ctx->qb.as<float>();
+    d.potentials = potentials ? ctx->pot.as<float>() : nullptr;
+    d.unary = ctx->unary.as<float>();
+    d.S = S;
+    FS_HIP(hipMemcpyAsync(ctx->descs.p, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    const CrfGeom geom{hp, wp, r, r, h, w, r};
     float *rows = ctx->rows.as<float>();
     for (int b = 0; b < B; ++b) {
         // pixel-major host tensors -> label planes
@@ -480,8 +560,7 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
         FS_HIP(hipMemcpyAsync(ctx->f2.p, f2 + (size_t)b * NP * 6, NP * 6 * 4, hipMemcpyHostToDevice, ctx->stream));
         FS_HIP(hipMemcpyAsync(ctx->f3.p, f3 + (size_t)b * NP * 5, NP * 5 * 4, hipMemcpyHostToDevice, ctx->stream));
         launch_crf_sim_explicit(ctx->f1.as<float>(), ctx->f2.as<float>(), ctx->f3.as<float>(), ctx->params, sim0, hp, wp, r, ctx->stream);
-        hipError_t e = launch_crf_iter(sim0, ctx->qa.as<float>(), ctx->qb.as<float>(), potentials ? ctx->pot.as<float>() : nullptr,
-                                       ctx->unary.as<float>(), nullptr, nullptr, nullptr, nullptr, S, f, ctx->params.weight, 0, ctx->stream);
+        hipError_t e = launch_crf_iter(ctx->descs.as<CrfFrameDesc>(), 1, crf_channel_class(S), geom, ctx->params.weight, 0, ctx->stream);
         if (e != hipSuccess) return ctx->fail(e, "fs_crf_step: launch");
         launch_planes_to_rows(ctx->qb.as<float>(), rows, NO, S, ctx->stream);
         FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, rows, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -519,16 +598,15 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
                     ctx->curv.as<uint8_t>(), true))                                                            // :513
         return -1;
-    int tiles_x, tiles_y;
-    crf_tile_grid(H, W, ctx->r, &tiles_x, &tiles_y);
-    const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
+    std::vector<int> S(n), maxa(n);
     for (int i = 0; i < n; ++i) {
         const int ns = ctx->counts_host[i] + 1;                                                                // :514
         if (num_surfaces) num_surfaces[i] = ns;
-        if (run_crf_frame(ctx, d_depth + i * N, d_rgb + i * N * 3, angles + i * N * 2, ctx->patches32.as<int32_t>() + i * N,
-                          ns + 1, 3, surfaces + i * N, ctx->tile_recs.as<int32_t>() + i * rec_stride, ctx->counts_host[n + i]))  // :515-532
-            return -1;
+        S[i] = ns + 1;
+        maxa[i] = ctx->counts_host[n + i];
     }
+    if (run_crf_batch(ctx, n, d_depth, d_rgb, angles, ctx->patches32.as<int32_t>(), S.data(), maxa.data(), 3, surfaces))   // :515-532
+        return -1;
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -582,18 +660,14 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
     int32_t *maxa = ctx->counts.as<int32_t>() + n;
     FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
-    launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, ctx->r, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+    launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
     ctx->counts_host.resize(2 * n);
     FS_HIP(hipMemcpyAsync(ctx->counts_host.data() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    int tiles_x, tiles_y;
-    crf_tile_grid(ctx->H, ctx->W, ctx->r, &tiles_x, &tiles_y);
-    const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
-    for (int i = 0; i < n; ++i)
-        if (run_crf_frame(ctx, ctx->depth16.as<uint16_t>() + i * N, ctx->rgb8.as<uint8_t>() + i * N * 3, ctx->angles.as<float>() + i * N * 2,
-                          ctx->patches32.as<int32_t>() + i * N, S[i], 1, ctx->surfaces64.as<int64_t>() + i * N,
-                          ctx->tile_recs.as<int32_t>() + i * rec_stride, ctx->counts_host[n + i]))
-            return -1;
+    std::vector<int> ma(ctx->counts_host.begin() + n, ctx->counts_host.end());
+    if (run_crf_batch(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), ctx->angles.as<float>(), ctx->patches32.as<int32_t>(),
+                      S.data(), ma.data(), 1, ctx->surfaces64.as<int64_t>()))
+        return -1;
     FS_HIP(hipMemcpyAsync(out, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;

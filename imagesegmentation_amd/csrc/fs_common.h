@@ -60,34 +60,44 @@ size_t cc_blocks_per_image(int H, int W);
 void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_size_exclusive, int64_t *labels64,
                                  int32_t *labels32, int n, int H, int W, hipStream_t st);
 // CRF (k_crf.hip)
-struct CrfFrame {            // one image (or one padded tile treated as an image)
-    int Hi, Wi;              // extent of Q / feature arrays
-    int oy, ox, oh, ow;      // output window inside the image
-    int S;                   // label channels
-    int r;                   // window radius
+struct CrfFrameDesc {            // one frame of a batched launch (device-resident array of these)
+    const float *sim0;           // similarity plane 0 of the frame (slack lies in front of it)
+    const float *Qin;            // label planes [S][Hi*Wi]
+    float *Qout;                 // label planes [S][oh*ow] or null
+    float *potentials;           // label planes [S][oh*ow] or null
+    const float *unary;          // explicit unary planes [S][oh*ow] or null (then synthesised from patches)
+    const int32_t *patches;      // [Hi*Wi] or null
+    const uint16_t *depth_raw;   // [Hi*Wi] or null: invalid-depth override
+    int64_t *surfaces;           // [oh*ow] or null: argmax output
+    const int32_t *tile_recs;    // per-tile active-label records or null (every label carried)
+    int S;                       // label channels
+    int pad_;
+};
+struct CrfGeom {                 // common to all frames of a launch
+    int Hi, Wi;                  // extent of Q / similarity / feature arrays
+    int oy, ox, oh, ow;          // output window inside the image
+    int r;                       // window radius
 };
 size_t crf_half_offsets(int r);
-size_t crf_sim_slack(int W, int r);      // floats of zeroed slack before and after the similarity planes
-int crf_tile_height(int r);              // rows per tile of the per-tile active-label records
-size_t crf_tile_rec_ints();              // ints per record
-void crf_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
+size_t crf_sim_slack(int W, int r);      // floats of zeroed slack in front of and behind a frame's planes
+size_t crf_tile_rec_ints();              // ints per per-tile record
+void crf_tile_grid(int H, int W, int *tiles_x, int *tiles_y);
+int crf_channel_class(int channels);     // kernel variant able to carry `channels` channels per tile
 void launch_crf_sim(const uint16_t *depth, const uint8_t *rgb, const float *angles, const CrfParams &p,
-                    const float *pos_terms, float *simH, int H, int W, int r, hipStream_t st);
+                    const float *pos_terms, float *simH, size_t sim_stride, int nframes, int H, int W, int r,
+                    hipStream_t st);
 void launch_crf_sim_explicit(const float *f1, const float *f2, const float *f3, const CrfParams &p, float *simH,
                              int Hi, int Wi, int r, hipStream_t st);
-void launch_crf_init(const int32_t *patches, float *Q, int H, int W, int S, hipStream_t st);
+void launch_crf_init(const CrfFrameDesc *descs, int nframes, int H, int W, hipStream_t st);   // writes descs[].Qin
 void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st);
 void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hipStream_t st);
-// patch labels present within `grow` pixels of every tile, for n frames; max_active[n] must be zeroed
-void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int r, int grow, int32_t *recs,
-                            int32_t *max_active, hipStream_t st);
+// patch labels present within `grow` pixels of every 64x16 tile, for n frames; max_active[n] must be zeroed
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int grow, int32_t *recs, int32_t *max_active,
+                            hipStream_t st);
 // mode bits for launch_crf_iter
 enum { CRF_LAST = 1 };
-// Q / potentials / unary are label planes.  tile_recs == nullptr: every label is carried (operator-level API);
-// otherwise max_channels = largest per-tile channel count (max active + 3).
-hipError_t launch_crf_iter(const float *simH, const float *Qin, float *Qout, float *potentials,
-                           const float *unary_explicit, const int32_t *patches, const uint16_t *depth_raw,
-                           int64_t *surfaces, const int32_t *tile_recs, int max_channels, const CrfFrame &f, float weight,
+// one mean-field update of nframes frames whose per-tile channel count fits `channel_class`
+hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
                            int mode, hipStream_t st);
 
 }  // namespace fs

@@ -25,11 +25,14 @@
 //   S planes.  In exact arithmetic this is the same update; in fp32 it differs
 //   from a dense evaluation by summation order only.
 //
-// crf_iter: one block = 64 x (4*PY) pixels, one wave per row group, each lane PY
-// vertically adjacent pixels, so that a neighbour's channel vector read from LDS
-// is used by up to PY pixels and consecutive lanes read consecutive 16-byte
-// slots (no bank conflicts).  Q of the tile + halo is staged in LDS 8 channels at a
-// time; the similarity planes stream from L2 with 256-byte wave loads.
+// crf_iter: one block = one 64 x 16 tile of one frame (blockIdx.z = frame of the
+// launch), 16/PY waves, each lane PY vertically adjacent pixels of one column.
+// Q of the tile + halo is staged in LDS as float4 channel quads, 8 channels per
+// pass, so consecutive lanes read consecutive 16-byte slots (no bank conflicts).
+// The window is walked by forward offset; at each offset a lane uses plane[p] for
+// the neighbour p+o and plane[p-o] for the neighbour p-o.  The second read is the
+// first read of the lane that owns p-o at the same step, so within a tile both
+// uses of a similarity value reach L2/HBM once.
 #include "fs_common.h"
 
 namespace fs {
@@ -50,15 +53,21 @@ __host__ __device__ __forceinline__ int half_index(int dy, int dx, int r)
 // depend on the offset only and come from pos_terms[offset][3].
 // exp() is evaluated as exp2(x * log2 e) on the hardware unit: its absolute error
 // on a value in (0, 1] stays below 3e-8, the size of one fp32 rounding.
+// blockIdx.z = frame; sim planes of frame z start at simH + z * sim_stride.
 // ---------------------------------------------------------------------------
 constexpr int STW = 64, STH = 4, SNT = STW * STH;
 
 __global__ __launch_bounds__(SNT) void crf_sim_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ rgb,
                                                       const float *__restrict__ angles, CrfParams P,
                                                       const float *__restrict__ pos_terms, float *__restrict__ simH,
-                                                      int H, int W, int r)
+                                                      size_t sim_stride, int H, int W, int r)
 {
     extern __shared__ float lds[];
+    const size_t N = (size_t)H * W;
+    depth += blockIdx.z * N;
+    rgb += blockIdx.z * N * 3;
+    angles += blockIdx.z * N * 2;
+    simH += blockIdx.z * sim_stride;
     const int LW = STW + 2 * r, LH = STH + r;
     const int plane = LW * LH;
     float *fd = lds, *fr = fd + plane, *fg = fr + plane, *fb = fg + plane, *fa0 = fb + plane, *fa1 = fa0 + plane;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(SNT) void crf_sim_kernel(const uint16_t *__restrict
     const int tx = threadIdx.x % STW, ty = threadIdx.x / STW;
     const int x = x0 + tx, y = y0 + ty;
     if (x >= W || y >= H) return;
-    const size_t N = (size_t)H * W, p = (size_t)y * W + x;
+    const size_t p = (size_t)y * W + x;
     const int ci = ty * LW + tx + r;
     const float dc = fd[ci], rc = fr[ci], gc = fg[ci], bc = fb[ci], a0c = fa0[ci], a1c = fa1[ci];
     const float nd = 6.0f, na = 2.0f, nc = (float)(1.0 / 50.0);   // similarity_normalizers, find_surfaces.py:20
@@ -149,14 +158,16 @@ __global__ __launch_bounds__(256) void crf_sim_explicit_kernel(const float *__re
 // ---------------------------------------------------------------------------
 // initial probabilities, get_unary_potentials_and_initial_probabilities
 // (find_surfaces.py:456-477): double arithmetic, cast to float like Keras does.
-// Writes label planes Q[l][p].
+// Writes label planes Q[l][p] of every frame of the launch (blockIdx.y = frame).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void crf_init_kernel(const int32_t *__restrict__ patches, float *__restrict__ Q, int N, int S)
+__global__ __launch_bounds__(256) void crf_init_kernel(const CrfFrameDesc *__restrict__ descs, int N)
 {
+    const CrfFrameDesc d = descs[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= N) return;
-    const int ns = S - 1;
-    const int lab = patches[p];
+    const int S = d.S, ns = S - 1;
+    const int lab = d.patches[p];
+    float *Q = const_cast<float *>(d.Qin);
     const float pv = (float)(1.0 / (double)ns);
     const float other = (float)(1.0 / (double)(ns - 1) * 0.1);
     for (int l = 0; l < S; ++l) {
@@ -189,11 +200,11 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const float *__rest
 // record (TILE_REC ints): [0] = count A, [4..7] = bit mask, [8..8+A) = labels
 // ascending.  max_active[frame] receives the largest A of the frame.
 // ---------------------------------------------------------------------------
-constexpr int ITW = 64;                       // tile width of the update kernel
+constexpr int ITW = 64, ITH = 16;             // tile of the update kernel
 constexpr int TILE_REC = kMaxLabels + 8;
 
-__global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tile_h,
-                                                              int grow, int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
+__global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int grow,
+                                                              int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
 {
     __shared__ unsigned mask[4];
     const int frame = blockIdx.z;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
     if (threadIdx.x < 4) mask[threadIdx.x] = 0u;
     __syncthreads();
     const int xa = max(0, (int)blockIdx.x * ITW - grow), xb = min(W, (int)(blockIdx.x + 1) * ITW + grow);
-    const int ya = max(0, (int)blockIdx.y * tile_h - grow), yb = min(H, (int)(blockIdx.y + 1) * tile_h + grow);
+    const int ya = max(0, (int)blockIdx.y * ITH - grow), yb = min(H, (int)(blockIdx.y + 1) * ITH + grow);
     const int rw = xb - xa;
     const int total = rw * (yb - ya);
     for (int i = threadIdx.x; i < total; i += 256) {
@@ -234,42 +245,28 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
 // ---------------------------------------------------------------------------
 // one mean-field update
 // ---------------------------------------------------------------------------
-struct IterArgs {
-    const float *simH;          // plane 0 (the buffer has slack in front of it)
-    const float *Qin;           // planes [S][Hi*Wi]
-    float *Qout;                // planes [S][oh*ow] or null
-    float *potentials;          // planes [S][oh*ow] or null
-    const float *unary;         // explicit planes [S][oh*ow] or null (then synthesised from patches)
-    const int32_t *patches;     // [Hi*Wi] or null
-    const uint16_t *depth_raw;  // [Hi*Wi] or null: invalid-depth override
-    int64_t *surfaces;          // [oh*ow] or null: argmax output
-    const int32_t *tile_recs;   // per-tile active-label records or null (all labels listed)
-    int rec_rows, rec_tiles_x;  // tile height the records were built for, records per tile row
-    CrfFrame f;
-    float weight;
-    int last;
-};
-
 template <int R, int PY, int NCH>
-__global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
+__global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g,
+                                                                 float weight, int last)
 {
-    constexpr int CH = 8;                 // channels staged per pass
-    constexpr int TH = 4 * PY;            // tile height
-    extern __shared__ float4 lds4[];      // [2][LH][LW] float4: channel quads of the staged pass
-    __shared__ int s_list[TILE_REC];      // [0]=CE [1]=n_rest [2]=rep_pos [4..7]=listed mask (without rep) [8..] labels
+    constexpr int CH = 8;                     // channels staged per pass
+    constexpr int NW = ITH / PY;              // waves per block
+    extern __shared__ float4 lds4[];          // [2][LH][LW] float4: channel quads of the staged pass
+    __shared__ int s_list[TILE_REC];          // [0]=CE [1]=n_rest [2]=rep_pos [4..7]=listed mask (without rep) [8..] labels
 
-    const int r = R ? R : a.f.r, S = a.f.S;
-    const int LW = ITW + 2 * r, LH = TH + 2 * r;
+    const CrfFrameDesc d = descs[blockIdx.z];
+    const int r = R ? R : g.r, S = d.S;
+    const int LW = ITW + 2 * r, LH = ITH + 2 * r;
     const int tid = threadIdx.x, tx = tid & 63, wv = tid >> 6;
-    const int wx0 = blockIdx.x * ITW, wy0 = blockIdx.y * TH;          // tile origin in the output window
-    const int ix0 = a.f.ox + wx0, iy0 = a.f.oy + wy0;                  // ... and in the image
-    const int Wi = a.f.Wi, Hi = a.f.Hi;
-    const size_t Ni = (size_t)Hi * Wi, No = (size_t)a.f.oh * a.f.ow;
+    const int wx0 = blockIdx.x * ITW, wy0 = blockIdx.y * ITH;         // tile origin in the output window
+    const int ix0 = g.ox + wx0, iy0 = g.oy + wy0;                      // ... and in the image
+    const int Wi = g.Wi, Hi = g.Hi;
+    const size_t Ni = (size_t)Hi * Wi, No = (size_t)g.oh * g.ow;
 
     // ---- channel list of this tile ----
-    if (a.tile_recs) {
-        const int32_t *rec = a.tile_recs + ((size_t)(wy0 / a.rec_rows) * a.rec_tiles_x + blockIdx.x) * TILE_REC;
-        for (int t = tid; t < TILE_REC; t += 256) s_list[t] = rec[t];
+    if (d.tile_recs) {
+        const int32_t *rec = d.tile_recs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE_REC;
+        for (int t = tid; t < TILE_REC; t += 64 * NW) s_list[t] = rec[t];
         __syncthreads();
         if (tid == 0) {
             // [0, active..., representative of the rest, S-1]
@@ -291,7 +288,7 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
             s_list[4] = (int)m[0]; s_list[5] = (int)m[1]; s_list[6] = (int)m[2]; s_list[7] = (int)m[3];
         }
     } else {
-        for (int t = tid; t < S; t += 256) s_list[8 + t] = t;
+        for (int t = tid; t < S; t += 64 * NW) s_list[8 + t] = t;
         if (tid == 0) { s_list[0] = S; s_list[1] = 0; s_list[2] = -1; }
         if (tid < 4) {
             const int lo = tid * 32;
@@ -305,7 +302,7 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
     // ---- per-lane pixels: column tx, rows wv*PY + i ----
     const int wx = wx0 + tx;
     const int gx = ix0 + tx;
-    const bool col_ok = wx < a.f.ow;
+    const bool col_ok = wx < g.ow;
     bool ok[PY], valid[PY];
     unsigned p[PY];     // pixel index in the image (< 2^31)
     size_t wi[PY];      // pixel index in the output window
@@ -313,11 +310,11 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
         const int wy = wy0 + wv * PY + i;
-        ok[i] = col_ok && wy < a.f.oh;
+        ok[i] = col_ok && wy < g.oh;
         const int gy = iy0 + wv * PY + i;
         p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
-        wi[i] = ok[i] ? (size_t)wy * a.f.ow + wx : 0;
-        valid[i] = ok[i] && !(a.depth_raw && a.depth_raw[p[i]] == 0);   // overridden pixels need no message
+        wi[i] = ok[i] ? (size_t)wy * g.ow + wx : 0;
+        valid[i] = ok[i] && !(d.depth_raw && d.depth_raw[p[i]] == 0);   // overridden pixels need no message
         any_work |= valid[i];
     }
     const bool wave_work = __ballot(any_work) != 0ull;
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
             int labs[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) labs[k] = ch * CH + k < CE ? s_list[8 + ch * CH + k] : -1;
-            for (int ly = wv; ly < LH; ly += 4) {
+            for (int ly = wv; ly < LH; ly += NW) {
                 const int gy = iy0 - r + ly;
                 const bool rowin = gy >= 0 && gy < Hi;
                 for (int lx = tx; lx < LW; lx += 64) {
@@ -348,42 +345,45 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
                     const size_t q = in ? (size_t)gy * Wi + gxx : 0;
                     float v[CH];
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) v[k] = (in && labs[k] >= 0) ? a.Qin[(size_t)labs[k] * Ni + q] : 0.0f;
+                    for (int k = 0; k < CH; ++k) v[k] = (in && labs[k] >= 0) ? d.Qin[(size_t)labs[k] * Ni + q] : 0.0f;
                     lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
                     lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
             __syncthreads();
             if (wave_work) {
-                // neighbour rows jr = 0 .. PY+2r-1 (LDS row wv*PY + jr); pixel i sees it at dy = jr - r - i
-                for (int jr = 0; jr < PY + 2 * r; ++jr) {
-                    const float4 *row0 = lds4 + (wv * PY + jr) * LW + tx + r;
-                    const float4 *row1 = row0 + plane4;
+                const float4 *qc = lds4 + (wv * PY + r) * LW + tx + r;     // centre of row i = 0
+                for (int dy = 0; dy <= r; ++dy) {
+                    const long base = dy == 0 ? -1 : r + (dy - 1) * (2 * r + 1) + r;   // plane of (dy, dx) = base + dx
 #pragma unroll
                     for (int dx = -r; dx <= r; ++dx) {
-                        float s[PY];
+                        if (dy == 0 && dx <= 0) continue;
+                        const float *plane = d.sim0 + (base + dx) * (long)Ni;
+                        const int sh = dy * Wi + dx;
+                        const int lo = dy * LW + dx;
 #pragma unroll
                         for (int i = 0; i < PY; ++i) {
-                            const int dy = jr - r - i;
-                            s[i] = 0.0f;
-                            if (dy >= -r && dy <= r && !(dy == 0 && dx == 0)) {
-                                const bool fwd = dy > 0 || (dy == 0 && dx > 0);
-                                const int oi = fwd ? half_index(dy, dx, r) : half_index(-dy, -dx, r);
-                                const float *pl = a.simH + ((long)oi * (long)Ni + (fwd ? 0l : (long)dy * Wi + dx));
-                                s[i] = pl[p[i]];
-                            }
-                        }
-                        const float4 q0 = row0[dx], q1 = row1[dx];
-#pragma unroll
-                        for (int i = 0; i < PY; ++i) {
-                            acc[ch][i][0] = fmaf(s[i], q0.x, acc[ch][i][0]);
-                            acc[ch][i][1] = fmaf(s[i], q0.y, acc[ch][i][1]);
-                            acc[ch][i][2] = fmaf(s[i], q0.z, acc[ch][i][2]);
-                            acc[ch][i][3] = fmaf(s[i], q0.w, acc[ch][i][3]);
-                            acc[ch][i][4] = fmaf(s[i], q1.x, acc[ch][i][4]);
-                            acc[ch][i][5] = fmaf(s[i], q1.y, acc[ch][i][5]);
-                            acc[ch][i][6] = fmaf(s[i], q1.z, acc[ch][i][6]);
-                            acc[ch][i][7] = fmaf(s[i], q1.w, acc[ch][i][7]);
+                            const float sf = plane[p[i]];                        // sim(p, p + o)
+                            const float sb = plane[(long)p[i] - sh];             // sim(p - o, p)
+                            const float4 *c = qc + i * LW;
+                            const float4 f0 = c[lo], f1 = c[plane4 + lo];
+                            const float4 b0 = c[-lo], b1 = c[plane4 - lo];
+                            acc[ch][i][0] = fmaf(sf, f0.x, acc[ch][i][0]);
+                            acc[ch][i][1] = fmaf(sf, f0.y, acc[ch][i][1]);
+                            acc[ch][i][2] = fmaf(sf, f0.z, acc[ch][i][2]);
+                            acc[ch][i][3] = fmaf(sf, f0.w, acc[ch][i][3]);
+                            acc[ch][i][4] = fmaf(sf, f1.x, acc[ch][i][4]);
+                            acc[ch][i][5] = fmaf(sf, f1.y, acc[ch][i][5]);
+                            acc[ch][i][6] = fmaf(sf, f1.z, acc[ch][i][6]);
+                            acc[ch][i][7] = fmaf(sf, f1.w, acc[ch][i][7]);
+                            acc[ch][i][0] = fmaf(sb, b0.x, acc[ch][i][0]);
+                            acc[ch][i][1] = fmaf(sb, b0.y, acc[ch][i][1]);
+                            acc[ch][i][2] = fmaf(sb, b0.z, acc[ch][i][2]);
+                            acc[ch][i][3] = fmaf(sb, b0.w, acc[ch][i][3]);
+                            acc[ch][i][4] = fmaf(sb, b1.x, acc[ch][i][4]);
+                            acc[ch][i][5] = fmaf(sb, b1.y, acc[ch][i][5]);
+                            acc[ch][i][6] = fmaf(sb, b1.z, acc[ch][i][6]);
+                            acc[ch][i][7] = fmaf(sb, b1.w, acc[ch][i][7]);
                         }
                     }
                 }
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
         if (!ok[i]) continue;
-        const bool invalid = a.depth_raw && !valid[i];
-        const int own = a.patches ? a.patches[p[i]] : 0;
+        const bool invalid = d.depth_raw && !valid[i];
+        const int own = d.patches ? d.patches[p[i]] : 0;
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
                 const int lab = s_list[8 + c];
                 const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
                 float un;
-                if (a.unary) un = a.unary[(size_t)lab * No + wi[i]];
+                if (d.unary) un = d.unary[(size_t)lab * No + wi[i]];
                 else un = lab == 0 ? 10.0f : ((own != 0 && lab == own) ? 0.0f : 1.0f);   // :459-472
-                const float add = un + a.weight * comp;            // :361
-                if (a.potentials) a.potentials[(size_t)lab * No + wi[i]] = add;
+                const float add = un + weight * comp;              // :361
+                if (d.potentials) d.potentials[(size_t)lab * No + wi[i]] = add;
                 if (c == rep_pos) add_rep = add;
                 m[c] = -add;
                 mx = fmaxf(mx, m[c]);
@@ -448,26 +448,26 @@ __global__ __launch_bounds__(256) void crf_iter_kernel(IterArgs a)
             if (c < CE) {
                 const int lab = s_list[8 + c];
                 float q = m[c] / den;
-                if (invalid) q = a.last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
+                if (invalid) q = last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
                 if (c == rep_pos) q_rep = q;
-                else if (a.Qout) a.Qout[(size_t)lab * No + wi[i]] = q;
+                else if (d.Qout) d.Qout[(size_t)lab * No + wi[i]] = q;
                 if (q > bestv || (q == bestv && lab < best)) { bestv = q; best = lab; }   // first maximum, :531
             }
         }
-        if (n_rest > 0 && (a.Qout || a.potentials)) {
+        if (n_rest > 0 && (d.Qout || d.potentials)) {
             // every unlisted label carries the representative's value
             for (int l = 1; l < S - 1; ++l) {
                 if ((unsigned)s_list[4 + (l >> 5)] >> (l & 31) & 1u) continue;
-                if (a.Qout) a.Qout[(size_t)l * No + wi[i]] = q_rep;
-                if (a.potentials) a.potentials[(size_t)l * No + wi[i]] = add_rep;
+                if (d.Qout) d.Qout[(size_t)l * No + wi[i]] = q_rep;
+                if (d.potentials) d.potentials[(size_t)l * No + wi[i]] = add_rep;
             }
         }
-        if (a.surfaces) a.surfaces[wi[i]] = best == S - 1 ? 0 : best;          // :532
+        if (d.surfaces) d.surfaces[wi[i]] = best == S - 1 ? 0 : best;          // :532
     }
 }
 
 template <int R, int PY, int NCH>
-hipError_t launch_iter_t(const IterArgs &a, size_t lds_bytes, hipStream_t st)
+hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, int last, hipStream_t st)
 {
     static bool attr_set = false;
     auto kern = crf_iter_kernel<R, PY, NCH>;
@@ -476,8 +476,9 @@ hipError_t launch_iter_t(const IterArgs &a, size_t lds_bytes, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((a.f.ow + ITW - 1) / ITW, (a.f.oh + 4 * PY - 1) / (4 * PY));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    const size_t lds = (size_t)2 * (ITW + 2 * g.r) * (ITH + 2 * g.r) * sizeof(float4);
+    dim3 grid((g.ow + ITW - 1) / ITW, (g.oh + ITH - 1) / ITH, nframes);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, last);
     return hipGetLastError();
 }
 
@@ -485,20 +486,26 @@ hipError_t launch_iter_t(const IterArgs &a, size_t lds_bytes, hipStream_t st)
 
 size_t crf_half_offsets(int r) { return (size_t)r + (size_t)r * (2 * r + 1); }
 size_t crf_sim_slack(int W, int r) { return (size_t)r * W + r; }
-int crf_tile_height(int r) { return r <= 7 ? 16 : 8; }
 size_t crf_tile_rec_ints() { return TILE_REC; }
-void crf_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)
+void crf_tile_grid(int H, int W, int *tiles_x, int *tiles_y)
 {
     *tiles_x = (W + ITW - 1) / ITW;
-    *tiles_y = (H + crf_tile_height(r) - 1) / crf_tile_height(r);
+    *tiles_y = (H + ITH - 1) / ITH;
+}
+int crf_channel_class(int channels)
+{
+    const int nch = (channels + 7) / 8;
+    if (nch <= 4) return nch;
+    if (nch <= 8) return 8;
+    return 16;
 }
 
 void launch_crf_sim(const uint16_t *depth, const uint8_t *rgb, const float *angles, const CrfParams &p,
-                    const float *pos_terms, float *simH, int H, int W, int r, hipStream_t st)
+                    const float *pos_terms, float *simH, size_t sim_stride, int nframes, int H, int W, int r, hipStream_t st)
 {
     const size_t lds = (size_t)(STW + 2 * r) * (STH + r) * 6 * sizeof(float);
-    dim3 grid((W + STW - 1) / STW, (H + STH - 1) / STH);
-    hipLaunchKernelGGL(crf_sim_kernel, grid, dim3(SNT), lds, st, depth, rgb, angles, p, pos_terms, simH, H, W, r);
+    dim3 grid((W + STW - 1) / STW, (H + STH - 1) / STH, nframes);
+    hipLaunchKernelGGL(crf_sim_kernel, grid, dim3(SNT), lds, st, depth, rgb, angles, p, pos_terms, simH, sim_stride, H, W, r);
 }
 
 void launch_crf_sim_explicit(const float *f1, const float *f2, const float *f3, const CrfParams &p, float *simH, int Hi,
@@ -508,10 +515,10 @@ void launch_crf_sim_explicit(const float *f1, const float *f2, const float *f3, 
     hipLaunchKernelGGL(crf_sim_explicit_kernel, grid, dim3(256), 0, st, f1, f2, f3, p, simH, Hi, Wi, r);
 }
 
-void launch_crf_init(const int32_t *patches, float *Q, int H, int W, int S, hipStream_t st)
+void launch_crf_init(const CrfFrameDesc *descs, int nframes, int H, int W, hipStream_t st)
 {
     const int N = H * W;
-    hipLaunchKernelGGL(crf_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, patches, Q, N, S);
+    hipLaunchKernelGGL(crf_init_kernel, dim3((N + 255) / 256, nframes), dim3(256), 0, st, descs, N);
 }
 
 void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st)
@@ -523,48 +530,41 @@ void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hi
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3((unsigned)((P * S + 255) / 256)), dim3(256), 0, st, planes, rows, (int)P, S);
 }
 
-void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int r, int grow, int32_t *recs, int32_t *max_active,
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int grow, int32_t *recs, int32_t *max_active,
                             hipStream_t st)
 {
     int tx, ty;
-    crf_tile_grid(H, W, r, &tx, &ty);
-    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, crf_tile_height(r), grow, recs, max_active);
+    crf_tile_grid(H, W, &tx, &ty);
+    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, grow, recs, max_active);
 }
 
-hipError_t launch_crf_iter(const float *simH, const float *Qin, float *Qout, float *potentials,
-                           const float *unary_explicit, const int32_t *patches, const uint16_t *depth_raw,
-                           int64_t *surfaces, const int32_t *tile_recs, int max_channels, const CrfFrame &f, float weight,
+hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
                            int mode, hipStream_t st)
 {
-    if (f.S < 2 || f.S > kMaxLabels || f.r < 1 || f.r > kMaxRadius) return hipErrorInvalidValue;
-    int tiles_x, tiles_y;
-    crf_tile_grid(f.oh, f.ow, f.r, &tiles_x, &tiles_y);
-    IterArgs a{simH, Qin, Qout, potentials, unary_explicit, patches, depth_raw, surfaces, tile_recs,
-               crf_tile_height(f.r), tiles_x, f, weight, (mode & CRF_LAST) ? 1 : 0};
-    const int ce = max_channels < f.S ? max_channels : f.S;
-    const int nch = (ce + 7) / 8;
-    auto lds = [&](int py) { return (size_t)2 * (ITW + 2 * f.r) * (4 * py + 2 * f.r) * sizeof(float4); };
-    // accumulators are NCH x PY x 8 registers per lane: fewer rows per lane when many channels are live
-    if (f.r == 7 && nch <= 4) {
-        switch (nch) {
-        case 1: return launch_iter_t<7, 4, 1>(a, lds(4), st);
-        case 2: return launch_iter_t<7, 4, 2>(a, lds(4), st);
-        case 3: return launch_iter_t<7, 4, 3>(a, lds(4), st);
-        default: return launch_iter_t<7, 4, 4>(a, lds(4), st);
+    if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
+    const int last = (mode & CRF_LAST) ? 1 : 0;
+    // accumulators are NCH x PY x 8 registers per lane: one row per lane when many channels are live
+    if (g.r == 7) {
+        switch (channel_class) {
+        case 1: return launch_iter_t<7, 2, 1>(descs, nframes, g, weight, last, st);
+        case 2: return launch_iter_t<7, 2, 2>(descs, nframes, g, weight, last, st);
+        case 3: return launch_iter_t<7, 2, 3>(descs, nframes, g, weight, last, st);
+        case 4: return launch_iter_t<7, 2, 4>(descs, nframes, g, weight, last, st);
+        case 8: return launch_iter_t<7, 2, 8>(descs, nframes, g, weight, last, st);
+        default: break;
+        }
+    } else {
+        switch (channel_class) {
+        case 1: return launch_iter_t<0, 2, 1>(descs, nframes, g, weight, last, st);
+        case 2: return launch_iter_t<0, 2, 2>(descs, nframes, g, weight, last, st);
+        case 3:
+        case 4: return launch_iter_t<0, 2, 4>(descs, nframes, g, weight, last, st);
+        case 8: return launch_iter_t<0, 2, 8>(descs, nframes, g, weight, last, st);
+        default: break;
         }
     }
-    if (f.r <= 7 && nch <= 4) {
-        if (nch == 1) return launch_iter_t<0, 4, 1>(a, lds(4), st);
-        if (nch == 2) return launch_iter_t<0, 4, 2>(a, lds(4), st);
-        return launch_iter_t<0, 4, 4>(a, lds(4), st);
-    }
-    if (nch <= 8) {
-        if (nch == 1) return launch_iter_t<0, 2, 1>(a, lds(2), st);
-        if (nch == 2) return launch_iter_t<0, 2, 2>(a, lds(2), st);
-        if (nch <= 4) return launch_iter_t<0, 2, 4>(a, lds(2), st);
-        return launch_iter_t<0, 2, 8>(a, lds(2), st);
-    }
-    return launch_iter_t<0, 1, 16>(a, lds(1), st);
+    if (channel_class == 16) return launch_iter_t<0, 1, 16>(descs, nframes, g, weight, last, st);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace fs
