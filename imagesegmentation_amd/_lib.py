@@ -12,7 +12,8 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfs_hip.so")
+# FS_HIP_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("FS_HIP_LIB") or os.path.join(_HERE, "libfs_hip.so")
 
 _c = ctypes
 _vp, _i, _d = _c.c_void_p, _c.c_int, _c.c_double

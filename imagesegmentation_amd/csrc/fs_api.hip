@@ -2,6 +2,7 @@
 // and the orchestration of the kernels in k_stencils.hip, k_cc.hip, k_crf.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/fs_hip.h"
@@ -27,13 +28,14 @@ struct fs_ctx {
     std::string err;
 
     // tables
-    DevBuf tanx, tany, ax, ay, pos_terms;
+    DevBuf tanx, tany, ax, ay, pos_terms, wtab;
+    bool use_planes = false;   // FS_CRF_PLANES=1: CRF update from precomputed similarity planes instead of the fused kernel
     // frame buffers, each sized for max_batch frames
     DevBuf depth16, rgb8, depthf, smoothed, points, normals, raw, angles, curv, scores, mask, edges, patches64, patches32,
         surfaces64;
     DevBuf cc_parent, cc_count, cc_newid, cc_blocksum;
     // CRF buffers (one frame in flight)
-    DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs;
+    DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
     std::vector<CrfFrameDesc> descs_host;
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
@@ -140,6 +142,19 @@ int build_pos_terms(fs_ctx *ctx)
         }
     FS_HIP(ctx->pos_terms.ensure(pt.size() * sizeof(float)));
     FS_HIP(hipMemcpy(ctx->pos_terms.p, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
+    // per-offset weights of the fused update: w_k * exp(-position term of kernel k) over the full window
+    const int kw = 2 * r + 1;
+    std::vector<float> wt((size_t)4 * kw * kw, 0.0f);
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const double q = ((double)dy / 40.0) * ((double)dy / 40.0) + ((double)dx / 40.0) * ((double)dx / 40.0);
+            float *w = &wt[4 * ((size_t)(dy + r) * kw + dx + r)];
+            w[0] = (float)(ctx->params.w1 * std::exp(-(double)ctx->params.t11 * q));
+            w[1] = (float)(ctx->params.w2 * std::exp(-(double)ctx->params.t21 * q));
+            w[2] = (float)(ctx->params.w3 * std::exp(-(double)ctx->params.t31 * q));
+        }
+    FS_HIP(ctx->wtab.ensure(wt.size() * sizeof(float)));
+    FS_HIP(hipMemcpy(ctx->wtab.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -169,9 +184,13 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_newid.ensure(n * N * 4));
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
     FS_HIP(ctx->counts.ensure(2 * n * 4));
-    int tx, ty;
-    crf_tile_grid(ctx->H, ctx->W, &tx, &ty);
-    FS_HIP(ctx->tile_recs.ensure(n * tx * ty * crf_tile_rec_ints() * 4));
+    if (crf_fused_tile_height(ctx->r)) {
+        int tx, ty;
+        crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
+        FS_HIP(ctx->tile_recs.ensure(n * tx * ty * crf_tile_rec_ints() * 4));
+        FS_HIP(ctx->featA.ensure(n * N * 16));
+        FS_HIP(ctx->featB.ensure(n * N * 8));
+    }
     return 0;
 }
 
@@ -207,9 +226,9 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
         // label counts and per-frame maxima
         int32_t *maxa = ctx->counts.as<int32_t>() + n;
         FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
-        {
+        if (const int th = crf_fused_tile_height(ctx->r)) {
             ScopedTimer t(ctx, G_INIT);
-            launch_crf_tile_active(d_patches32, n, H, W, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+            launch_crf_tile_active(d_patches32, n, H, W, 32, th, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
         }
         ctx->counts_host.resize(2 * n);
         FS_HIP(hipMemcpyAsync(ctx->counts_host.data(), ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -244,15 +263,16 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
 {
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
-    int tiles_x, tiles_y;
-    crf_tile_grid(H, W, &tiles_x, &tiles_y);
+    const bool fused = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;
+    int tiles_x = 0, tiles_y = 0;
+    if (fused) crf_fused_tile_grid(H, W, ctx->r, &tiles_x, &tiles_y);
     const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
     for (int i = 0; i < n; ++i)
         if (S[i] > kMaxLabels) return ctx->fail("frame has " + std::to_string(S[i]) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
     const int G = n < kCrfGroup ? n : kCrfGroup;
     float *sim0 = nullptr;
     size_t sim_stride = 0;
-    if (ensure_sim(ctx, N, W, G, &sim0, &sim_stride)) return -1;
+    if (!fused && ensure_sim(ctx, N, W, G, &sim0, &sim_stride)) return -1;
     size_t qmax = 0;
     for (int g0 = 0; g0 < n; g0 += G) {
         size_t q = 0;
@@ -274,7 +294,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
         size_t q = 0;
         for (int k = 0; k < gn; ++k) {
             order[k] = k;
-            int ce = max_active[g0 + k] + 3;
+            int ce = fused ? max_active[g0 + k] + 3 : S[g0 + k];   // without per-tile lists every label is carried
             if (ce > S[g0 + k]) ce = S[g0 + k];
             cls[k] = crf_channel_class(ce);
             qoff[k] = q;
@@ -289,7 +309,9 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             for (int k = 0; k < gn; ++k) {
                 const int f = order[k], fi = g0 + f;
                 CrfFrameDesc &d = dh[base + k];
-                d.sim0 = sim0 + (size_t)f * sim_stride;
+                d.sim0 = fused ? nullptr : sim0 + (size_t)f * sim_stride;
+                d.featA = fused ? ctx->featA.as<float4>() + (size_t)fi * N : nullptr;
+                d.featB = fused ? ctx->featB.as<float2>() + (size_t)fi * N : nullptr;
                 d.Qin = qin + qoff[f];
                 d.Qout = last ? nullptr : qout + qoff[f];
                 d.potentials = nullptr;
@@ -297,7 +319,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                 d.patches = d_labels32 + (size_t)fi * N;
                 d.depth_raw = d_depth + (size_t)fi * N;
                 d.surfaces = last ? d_surfaces + (size_t)fi * N : nullptr;
-                d.tile_recs = ctx->tile_recs.as<int32_t>() + (size_t)fi * rec_stride;
+                d.tile_recs = fused ? ctx->tile_recs.as<int32_t>() + (size_t)fi * rec_stride : nullptr;
                 d.S = S[fi];
                 if (k == 0 || cls[order[k]] != cls[order[k - 1]])
                     launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f]});
@@ -310,22 +332,27 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     FS_HIP(hipMemcpyAsync(ctx->descs.p, dh.data(), dh.size() * sizeof(CrfFrameDesc), hipMemcpyHostToDevice, ctx->stream));
     const CrfFrameDesc *dd = ctx->descs.as<CrfFrameDesc>();
     const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
+    if (fused) {
+        ScopedTimer t(ctx, G_SIM);
+        launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->stream);
+    }
     for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
         const int gn = (n - g0) < G ? (n - g0) : G;
-        {
+        if (!fused) {
             ScopedTimer t(ctx, G_SIM);
             launch_crf_sim(d_depth + (size_t)g0 * N, d_rgb + (size_t)g0 * N * 3, d_angles + (size_t)g0 * N * 2, ctx->params,
                            ctx->pos_terms.as<float>(), sim0, sim_stride, gn, H, W, ctx->r, ctx->stream);
         }
-        {
+        if (!fused) {
             ScopedTimer t(ctx, G_INIT);
             launch_crf_init(dd + (size_t)g0 * iterations, gn, H, W, ctx->stream);
         }
         for (int it = 0; it < iterations; ++it) {
             ScopedTimer t(ctx, G_ITER);
             for (const Launch &l : launches[(size_t)gi * iterations + it]) {
-                hipError_t e = launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight,
-                                               it == iterations - 1 ? CRF_LAST : 0, ctx->stream);
+                const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
+                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, ctx->stream)
+                                     : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }
         }
@@ -364,6 +391,7 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(0); }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
     ctx->stream = ctx->own_stream;
+    if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
     *out = ctx;
@@ -375,11 +403,11 @@ void fs_destroy(fs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
+    DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->tile_recs, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs};
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -660,7 +688,8 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
     int32_t *maxa = ctx->counts.as<int32_t>() + n;
     FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
-    launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+    if (const int th = crf_fused_tile_height(ctx->r))
+        launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, 32, th, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
     ctx->counts_host.resize(2 * n);
     FS_HIP(hipMemcpyAsync(ctx->counts_host.data() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));

@@ -67,7 +67,9 @@ struct CrfFrameDesc {            // one frame of a batched launch (device-reside
     float *potentials;           // label planes [S][oh*ow] or null
     const float *unary;          // explicit unary planes [S][oh*ow] or null (then synthesised from patches)
     const int32_t *patches;      // [Hi*Wi] or null
-    const uint16_t *depth_raw;   // [Hi*Wi] or null: invalid-depth override
+    const uint16_t *depth_raw;   // [Hi*Wi] or null: invalid-depth override (and depth feature of the fused update)
+    const float4 *featA;         // fused update: [Hi*Wi] (depth, r, g, b) as floats, or null
+    const float2 *featB;         // fused update: [Hi*Wi] (angle0, angle1), or null
     int64_t *surfaces;           // [oh*ow] or null: argmax output
     const int32_t *tile_recs;    // per-tile active-label records or null (every label carried)
     int S;                       // label channels
@@ -91,13 +93,23 @@ void launch_crf_sim_explicit(const float *f1, const float *f2, const float *f3, 
 void launch_crf_init(const CrfFrameDesc *descs, int nframes, int H, int W, hipStream_t st);   // writes descs[].Qin
 void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st);
 void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hipStream_t st);
-// patch labels present within `grow` pixels of every 64x16 tile, for n frames; max_active[n] must be zeroed
-void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int grow, int32_t *recs, int32_t *max_active,
-                            hipStream_t st);
+// patch labels present within `grow` pixels of every tile_w x tile_h tile, for n frames; max_active[n] must be zeroed
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
+                            int32_t *max_active, hipStream_t st);
 // mode bits for launch_crf_iter
-enum { CRF_LAST = 1 };
+enum { CRF_LAST = 1, CRF_FIRST = 2 };
 // one mean-field update of nframes frames whose per-tile channel count fits `channel_class`
 hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
                            int mode, hipStream_t st);
+// same update with the similarity evaluated in the kernel from descs[].featA / featB (no similarity planes);
+// wtab = per-offset weights [(2r+1)^2][4] = (w1', w2', w3', 0)
+int crf_fused_tile_height(int r);        // 16 or 8 rows (tile width 32), 0 if the window is too large for the fused kernel
+void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
+void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
+                              size_t total, hipStream_t st);
+// CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
+// planes of a tile's listed labels and of its representative are written (see k_crf.hip).
+hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
+                                 const CrfParams &P, const float *wtab, int mode, hipStream_t st);
 
 }  // namespace fs

@@ -34,10 +34,16 @@
 // first read of the lane that owns p-o at the same step, so within a tile both
 // uses of a similarity value reach L2/HBM once.
 #include "fs_common.h"
+#ifndef FS_SKIPMAIN
+#define FS_SKIPMAIN 0
+#endif
 
 namespace fs {
 
 namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));      // packed pair: arithmetic lowers to v_pk_*_f32
+typedef __attribute__((address_space(1))) float gfloat;   // pointer known to be global: saddr + 32-bit offset loads
 
 __device__ __forceinline__ float div_no_nan(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
 
@@ -203,8 +209,9 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const float *__rest
 constexpr int ITW = 64, ITH = 16;             // tile of the update kernel
 constexpr int TILE_REC = kMaxLabels + 8;
 
-__global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int grow,
-                                                              int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
+__global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tw, int th,
+                                                              int grow, int32_t *__restrict__ recs,
+                                                              int32_t *__restrict__ max_active)
 {
     __shared__ unsigned mask[4];
     const int frame = blockIdx.z;
@@ -213,8 +220,8 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
     int32_t *rec = recs + ((size_t)frame * tiles_x * tiles_y + (size_t)blockIdx.y * tiles_x + blockIdx.x) * TILE_REC;
     if (threadIdx.x < 4) mask[threadIdx.x] = 0u;
     __syncthreads();
-    const int xa = max(0, (int)blockIdx.x * ITW - grow), xb = min(W, (int)(blockIdx.x + 1) * ITW + grow);
-    const int ya = max(0, (int)blockIdx.y * ITH - grow), yb = min(H, (int)(blockIdx.y + 1) * ITH + grow);
+    const int xa = max(0, (int)blockIdx.x * tw - grow), xb = min(W, (int)(blockIdx.x + 1) * tw + grow);
+    const int ya = max(0, (int)blockIdx.y * th - grow), yb = min(H, (int)(blockIdx.y + 1) * th + grow);
     const int rw = xb - xa;
     const int total = rw * (yb - ya);
     for (int i = threadIdx.x; i < total; i += 256) {
@@ -243,33 +250,19 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------
-// one mean-field update
+// one mean-field update: shared pieces
 // ---------------------------------------------------------------------------
-template <int R, int PY, int NCH>
-__global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g,
-                                                                 float weight, int last)
+// Channel list of a tile in LDS: s_list[0]=CE, [1]=n_rest, [2]=rep_pos, [4..7]=bit mask of the
+// listed labels (without the representative), [8..8+CE) = labels [0, listed..., representative, S-1].
+template <int NT>
+__device__ __forceinline__ void build_channel_list(int *s_list, const int32_t *tile_recs, int tile, int S)
 {
-    constexpr int CH = 8;                     // channels staged per pass
-    constexpr int NW = ITH / PY;              // waves per block
-    extern __shared__ float4 lds4[];          // [2][LH][LW] float4: channel quads of the staged pass
-    __shared__ int s_list[TILE_REC];          // [0]=CE [1]=n_rest [2]=rep_pos [4..7]=listed mask (without rep) [8..] labels
-
-    const CrfFrameDesc d = descs[blockIdx.z];
-    const int r = R ? R : g.r, S = d.S;
-    const int LW = ITW + 2 * r, LH = ITH + 2 * r;
-    const int tid = threadIdx.x, tx = tid & 63, wv = tid >> 6;
-    const int wx0 = blockIdx.x * ITW, wy0 = blockIdx.y * ITH;         // tile origin in the output window
-    const int ix0 = g.ox + wx0, iy0 = g.oy + wy0;                      // ... and in the image
-    const int Wi = g.Wi, Hi = g.Hi;
-    const size_t Ni = (size_t)Hi * Wi, No = (size_t)g.oh * g.ow;
-
-    // ---- channel list of this tile ----
-    if (d.tile_recs) {
-        const int32_t *rec = d.tile_recs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TILE_REC;
-        for (int t = tid; t < TILE_REC; t += 64 * NW) s_list[t] = rec[t];
+    const int tid = threadIdx.x;
+    if (tile_recs) {
+        const int32_t *rec = tile_recs + (size_t)tile * TILE_REC;
+        for (int t = tid; t < TILE_REC; t += NT) s_list[t] = rec[t];
         __syncthreads();
         if (tid == 0) {
-            // [0, active..., representative of the rest, S-1]
             const int A = s_list[0];
             unsigned m[4] = {(unsigned)s_list[4], (unsigned)s_list[5], (unsigned)s_list[6], (unsigned)s_list[7]};
             for (int i = A - 1; i >= 0; --i) s_list[9 + i] = s_list[8 + i];
@@ -288,7 +281,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
             s_list[4] = (int)m[0]; s_list[5] = (int)m[1]; s_list[6] = (int)m[2]; s_list[7] = (int)m[3];
         }
     } else {
-        for (int t = tid; t < S; t += 64 * NW) s_list[8 + t] = t;
+        for (int t = tid; t < S; t += NT) s_list[8 + t] = t;
         if (tid == 0) { s_list[0] = S; s_list[1] = 0; s_list[2] = -1; }
         if (tid < 4) {
             const int lo = tid * 32;
@@ -297,7 +290,130 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
         }
     }
     __syncthreads();
+}
+
+// Stage channels [c0, c0+8) of Q for the tile + halo into LDS as two float4 planes.
+template <int NW>
+__device__ __forceinline__ void stage_q(float4 *lds4, const int *s_list, const float *Qin, int c0, int CE, int iy0, int ix0,
+                                        int r, int LW, int LH, int Hi, int Wi, size_t Ni)
+{
+    const int tx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int plane4 = LH * LW;
+    int labs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) labs[k] = c0 + k < CE ? s_list[8 + c0 + k] : -1;
+    for (int ly = wv; ly < LH; ly += NW) {
+        const int gy = iy0 - r + ly;
+        const bool rowin = gy >= 0 && gy < Hi;
+        for (int lx = tx; lx < LW; lx += 64) {
+            const int gxx = ix0 - r + lx;
+            const bool in = rowin && gxx >= 0 && gxx < Wi;
+            const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (in && labs[k] >= 0) ? Qin[(size_t)labs[k] * Ni + q] : 0.0f;
+            lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
+            lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// Potts compatibility, softmax, overrides and expansion to S planes for one pixel.
+// m[c] = message of channel c (c < CE).
+template <int NC, bool COMPACT>
+__device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, const CrfFrameDesc &d, int S, size_t No,
+                                             size_t wi, unsigned p, bool invalid, float weight, int last)
+{
     const int CE = s_list[0], n_rest = s_list[1], rep_pos = s_list[2];
+    const float pv = (float)(1.0 / (double)(S - 1));
+    const int own = d.patches ? d.patches[p] : 0;
+    // evidence of the constant "unassigned" input: 0.00005 * onehot(S-1)   (find_surfaces.py:356-357, 451-452)
+    // total over all S labels (the representative counts n_rest times), compensated so that
+    // compatibility[l] = total - msg[l] keeps full relative accuracy
+    float tot = 0.0f, tot_lo = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            if (c == CE - 1) m[c] = m[c] + 0.00005f;
+            const float term = c == rep_pos ? m[c] * (float)n_rest : m[c];
+            const float t = tot + term;
+            const float bp = t - tot;
+            tot_lo += (tot - (t - bp)) + (term - bp);
+            tot = t;
+        }
+    }
+    float mx = -INFINITY, add_rep = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            const int lab = s_list[8 + c];
+            const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
+            float un;
+            if (d.unary) un = d.unary[(size_t)lab * No + wi];
+            else un = lab == 0 ? 10.0f : ((own != 0 && lab == own) ? 0.0f : 1.0f);   // :459-472
+            const float add = un + weight * comp;              // :361
+            if (d.potentials) d.potentials[(size_t)lab * No + wi] = add;
+            if (c == rep_pos) add_rep = add;
+            m[c] = -add;
+            mx = fmaxf(mx, m[c]);
+        }
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            m[c] = expf(m[c] - mx);                             // softmax(-add), :363
+            den = den + (c == rep_pos ? m[c] * (float)n_rest : m[c]);
+        }
+    }
+    float q_rep = 0.0f;
+    int best = 0;
+    float bestv = -1.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            const int lab = s_list[8 + c];
+            float q = m[c] / den;
+            if (invalid) q = last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
+            if (c == rep_pos && !COMPACT) q_rep = q;                 // written with the other unlisted labels below
+            else if (d.Qout) d.Qout[(size_t)lab * No + wi] = q;
+            if (q > bestv || (q == bestv && lab < best)) { bestv = q; best = lab; }   // first maximum, :531
+        }
+    }
+    if (!COMPACT && n_rest > 0 && (d.Qout || d.potentials)) {
+        // every unlisted label carries the representative's value
+        for (int l = 1; l < S - 1; ++l) {
+            if ((unsigned)s_list[4 + (l >> 5)] >> (l & 31) & 1u) continue;
+            if (d.Qout) d.Qout[(size_t)l * No + wi] = q_rep;
+            if (d.potentials) d.potentials[(size_t)l * No + wi] = add_rep;
+        }
+    }
+    if (d.surfaces) d.surfaces[wi] = best == S - 1 ? 0 : best;          // :532
+}
+
+// ---------------------------------------------------------------------------
+// update with precomputed similarity planes (operator-level API: arbitrary feature tensors)
+// ---------------------------------------------------------------------------
+template <int R, int PY, int NCH>
+__global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g,
+                                                                 float weight, int last)
+{
+    constexpr int CH = 8;                     // channels staged per pass
+    constexpr int NW = ITH / PY;              // waves per block
+    extern __shared__ float4 lds4[];          // [2][LH][LW] float4: channel quads of the staged pass
+    __shared__ int s_list[TILE_REC];
+
+    const CrfFrameDesc d = descs[blockIdx.z];
+    const int r = R ? R : g.r, S = d.S;
+    const int LW = ITW + 2 * r, LH = ITH + 2 * r;
+    const int tid = threadIdx.x, tx = tid & 63, wv = tid >> 6;
+    const int wx0 = blockIdx.x * ITW, wy0 = blockIdx.y * ITH;         // tile origin in the output window
+    const int ix0 = g.ox + wx0, iy0 = g.oy + wy0;                      // ... and in the image
+    const int Wi = g.Wi, Hi = g.Hi;
+    const size_t Ni = (size_t)Hi * Wi, No = (size_t)g.oh * g.ow;
+
+    build_channel_list<64 * NW>(s_list, d.tile_recs, blockIdx.y * gridDim.x + blockIdx.x, S);
+    const int CE = s_list[0];
 
     // ---- per-lane pixels: column tx, rows wv*PY + i ----
     const int wx = wx0 + tx;
@@ -332,33 +448,17 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch * CH < CE) {
             if (ch > 0) __syncthreads();
-            // stage channels [ch*8, ch*8+8) of the tile + halo; rows by wave, columns by lane
-            int labs[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) labs[k] = ch * CH + k < CE ? s_list[8 + ch * CH + k] : -1;
-            for (int ly = wv; ly < LH; ly += NW) {
-                const int gy = iy0 - r + ly;
-                const bool rowin = gy >= 0 && gy < Hi;
-                for (int lx = tx; lx < LW; lx += 64) {
-                    const int gxx = ix0 - r + lx;
-                    const bool in = rowin && gxx >= 0 && gxx < Wi;
-                    const size_t q = in ? (size_t)gy * Wi + gxx : 0;
-                    float v[CH];
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) v[k] = (in && labs[k] >= 0) ? d.Qin[(size_t)labs[k] * Ni + q] : 0.0f;
-                    lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
-                    lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            }
+            stage_q<NW>(lds4, s_list, d.Qin, ch * CH, CE, iy0, ix0, r, LW, LH, Hi, Wi, Ni);
             __syncthreads();
             if (wave_work) {
                 const float4 *qc = lds4 + (wv * PY + r) * LW + tx + r;     // centre of row i = 0
+                const gfloat *sim0 = (const gfloat *)d.sim0;
                 for (int dy = 0; dy <= r; ++dy) {
                     const long base = dy == 0 ? -1 : r + (dy - 1) * (2 * r + 1) + r;   // plane of (dy, dx) = base + dx
 #pragma unroll
                     for (int dx = -r; dx <= r; ++dx) {
                         if (dy == 0 && dx <= 0) continue;
-                        const float *plane = d.sim0 + (base + dx) * (long)Ni;
+                        const gfloat *plane = sim0 + (base + dx) * (long)Ni;
                         const int sh = dy * Wi + dx;
                         const int lo = dy * LW + dx;
 #pragma unroll
@@ -391,79 +491,257 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
         }
     }
 
-    // ---- Potts compatibility, softmax, overrides, expansion to S planes ----
-    const float pv = (float)(1.0 / (double)(S - 1));
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
         if (!ok[i]) continue;
-        const bool invalid = d.depth_raw && !valid[i];
-        const int own = d.patches ? d.patches[p[i]] : 0;
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        // evidence of the constant "unassigned" input: 0.00005 * onehot(S-1)   (find_surfaces.py:356-357, 451-452)
-        // total over all S labels (the representative counts n_rest times), compensated so that
-        // compatibility[l] = total - msg[l] keeps full relative accuracy
-        float tot = 0.0f, tot_lo = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) {
-            if (c < CE) {
-                if (c == CE - 1) m[c] = m[c] + 0.00005f;
-                const float term = c == rep_pos ? m[c] * (float)n_rest : m[c];
-                const float t = tot + term;
-                const float bp = t - tot;
-                tot_lo += (tot - (t - bp)) + (term - bp);
-                tot = t;
-            }
-        }
-        float mx = -INFINITY, add_rep = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) {
-            if (c < CE) {
-                const int lab = s_list[8 + c];
-                const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
-                float un;
-                if (d.unary) un = d.unary[(size_t)lab * No + wi[i]];
-                else un = lab == 0 ? 10.0f : ((own != 0 && lab == own) ? 0.0f : 1.0f);   // :459-472
-                const float add = un + weight * comp;              // :361
-                if (d.potentials) d.potentials[(size_t)lab * No + wi[i]] = add;
-                if (c == rep_pos) add_rep = add;
-                m[c] = -add;
-                mx = fmaxf(mx, m[c]);
-            }
-        }
-        float den = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) {
-            if (c < CE) {
-                m[c] = expf(m[c] - mx);                             // softmax(-add), :363
-                den = den + (c == rep_pos ? m[c] * (float)n_rest : m[c]);
-            }
-        }
-        float q_rep = 0.0f;
-        int best = 0;
-        float bestv = -1.0f;
-#pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) {
-            if (c < CE) {
-                const int lab = s_list[8 + c];
-                float q = m[c] / den;
-                if (invalid) q = last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
-                if (c == rep_pos) q_rep = q;
-                else if (d.Qout) d.Qout[(size_t)lab * No + wi[i]] = q;
-                if (q > bestv || (q == bestv && lab < best)) { bestv = q; best = lab; }   // first maximum, :531
-            }
-        }
-        if (n_rest > 0 && (d.Qout || d.potentials)) {
-            // every unlisted label carries the representative's value
-            for (int l = 1; l < S - 1; ++l) {
-                if ((unsigned)s_list[4 + (l >> 5)] >> (l & 31) & 1u) continue;
-                if (d.Qout) d.Qout[(size_t)l * No + wi[i]] = q_rep;
-                if (d.potentials) d.potentials[(size_t)l * No + wi[i]] = add_rep;
-            }
-        }
-        if (d.surfaces) d.surfaces[wi[i]] = best == S - 1 ? 0 : best;          // :532
+        finish_pixel<NCH * CH, false>(m, s_list, d, S, No, wi[i], p[i], d.depth_raw && !valid[i], weight, last);
     }
+}
+
+// ---------------------------------------------------------------------------
+// update with the similarity evaluated in the kernel (fused path).
+//
+// Streaming precomputed similarities costs ~250 MB of HBM reads per frame and update, which
+// is what bounds the plane-based kernel; the six feature values of tile + halo fit in LDS next
+// to Q, so here every lane evaluates sim(p, q) itself:
+//   sim = w1'[o] 2^-(K1 u) + w2'[o] 2^-(K2 u + C2 |dc|^2) + w3'[o] 2^-(K3 u + C3 |da|^2) + bias
+//   u = ((dq - dp) / (dp + dq))^2  (0 when both depths are 0),
+// the reference's three Gaussian kernels (find_surfaces.py:343-355) with the normalisers and
+// squared thetas folded into K*, C* and log2(e), and the offset-dependent position terms folded
+// into per-offset weights w'[o] = w exp(-position term).
+//
+// Tile 32 x TH pixels, 4 waves; a lane owns two vertically adjacent pixels and keeps them as
+// packed pairs, so the arithmetic is v_pk_*_f32 and one LDS read of a neighbour's features and
+// channel vector serves both pixels (the window is walked by neighbour row).
+//
+// Q is kept compact in HBM: a tile writes only the planes of its listed labels and of its
+// representative.  A tile that lists a label its neighbour tile does not list reads the
+// neighbour's representative plane for the halo pixels that lie in the neighbour (s_src).
+// On the first update Q is synthesised from the patch labels
+// (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
+// ---------------------------------------------------------------------------
+struct FusedConsts { float K1, K2, K3, C2, C3, bias; };
+constexpr int FTW = 32;                       // tile width of the fused kernel
+
+template <int R, int TH, int NCH>
+__global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
+                                                             const float4 *__restrict__ wtab, float weight, int first, int last)
+{
+    constexpr int CH = 8;
+    static_assert(TH == 16 || TH == 8, "tile height");
+    extern __shared__ float4 lds4[];          // [2][LH][LW] Q quads | [LH][LW] (d,r,g,b) | [LH][LW] (a0,a1) as float2
+    __shared__ int s_list[TILE_REC];
+    __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
+
+    const CrfFrameDesc d = descs[blockIdx.z];
+    const int r = R ? R : g.r, S = d.S;
+    const int LW = FTW + 2 * r, LH = TH + 2 * r;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ix0 = blockIdx.x * FTW, iy0 = blockIdx.y * TH;            // fused path: output window = frame
+    const int Wi = g.Wi, Hi = g.Hi;
+    const size_t Ni = (size_t)Hi * Wi;
+    const int plane4 = LH * LW;
+    float4 *featA = lds4 + 2 * plane4;
+    float2 *featB = reinterpret_cast<float2 *>(featA + plane4);
+    const int tiles_x = gridDim.x, tiles_y = gridDim.y;
+
+    build_channel_list<256>(s_list, d.tile_recs, blockIdx.y * tiles_x + blockIdx.x, S);
+    const int CE = s_list[0];
+
+    // ---- where to read each of my channels in the nine tiles the staged region touches ----
+    if (!first && tid < 15) {
+        const int sy = (int)blockIdx.y + tid / 3 - 2, sx = (int)blockIdx.x + tid % 3 - 1;
+        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
+            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
+        } else {
+            const int32_t *rec = d.tile_recs + ((size_t)sy * tiles_x + sx) * TILE_REC;
+            const unsigned m[4] = {(unsigned)rec[4], (unsigned)rec[5], (unsigned)rec[6], (unsigned)rec[7]};
+            int rep = 1;                                            // representative of the source tile
+            while (rep < S - 1 && (m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
+            for (int c = 0; c < CE; ++c) {
+                const int l = s_list[8 + c];
+                const bool listed = l == 0 || l == S - 1 || (m[l >> 5] >> (l & 31) & 1u);
+                s_src[tid][c] = listed ? l : rep;
+            }
+        }
+    }
+
+    // ---- features of tile + halo (zero outside the frame, like the reference's padded feature maps) ----
+    for (int ly = wv; ly < LH; ly += 4) {
+        const int gy = iy0 - r + ly;
+        const bool rowin = gy >= 0 && gy < Hi;
+        for (int lx = lane; lx < LW; lx += 64) {
+            const int gxx = ix0 - r + lx;
+            float4 fa = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 fb = make_float2(0.f, 0.f);
+            if (rowin && gxx >= 0 && gxx < Wi) {
+                const size_t q = (size_t)gy * Wi + gxx;
+                fa = d.featA[q];
+                fb = d.featB[q];
+            }
+            featA[ly * LW + lx] = fa;
+            featB[ly * LW + lx] = fb;
+        }
+    }
+
+    // ---- per-lane pixel pair: column lane & 31, rows (wave, lane half) ----
+    const int col = lane & 31, half = lane >> 5;
+    // TH = 16: wave covers rows 4*wv .. 4*wv+3, half 0 -> rows 4wv, 4wv+1; half 1 -> 4wv+2, 4wv+3
+    // TH = 8 : wave covers rows 2*wv, 2*wv+1 for half 0 only (half 1 idles)
+    const int trow = TH == 16 ? wv * 4 + half * 2 : wv * 2;
+    const bool lane_on = TH == 16 || half == 0;
+    const int gx = ix0 + col;
+    bool ok[2], valid[2];
+    unsigned p[2];
+    bool any_work = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gy = iy0 + trow + i;
+        ok[i] = lane_on && gx < Wi && gy < Hi;
+        p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
+        valid[i] = ok[i] && d.depth_raw[p[i]] != 0;        // overridden pixels need no message
+        any_work |= valid[i];
+    }
+    const bool wave_work = __ballot(any_work) != 0ull;
+
+    float acc[NCH][2][CH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[c][i][k] = 0.0f;
+
+    const int kw = 2 * r + 1;
+    const int ns = S - 1;
+    const float q_pv = (float)(1.0 / (double)ns), q_other = (float)(1.0 / (double)(ns - 1) * 0.1);
+    __syncthreads();                                        // s_src, features
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch * CH < CE) {
+            if (ch > 0) __syncthreads();
+            // ---- stage channels [ch*8, ch*8+8) of Q for tile + halo ----
+            for (int ly = wv; ly < LH; ly += 4) {
+                const int gy = iy0 - r + ly;
+                const bool rowin = gy >= 0 && gy < Hi;
+                const int sy = ((gy >> (TH == 16 ? 4 : 3)) - (int)blockIdx.y + 2) * 3;
+                for (int lx = lane; lx < LW; lx += 64) {
+                    const int gxx = ix0 - r + lx;
+                    const bool in = rowin && gxx >= 0 && gxx < Wi;
+                    const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+                    float v[CH];
+                    if (first) {
+                        const int lab = in ? d.patches[q] : -1;
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const int l = ch * CH + k < CE ? s_list[8 + ch * CH + k] : -1;
+                            float x = 0.0f;
+                            if (lab >= 0 && l > 0) x = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
+                            v[k] = x;
+                        }
+                    } else {
+                        const int st = sy + ((gxx >> 5) - (int)blockIdx.x + 1);
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
+                            v[k] = l >= 0 ? d.Qin[(size_t)l * Ni + q] : 0.0f;
+                        }
+                    }
+                    lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
+                    lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __syncthreads();
+            if (wave_work && FS_SKIPMAIN == 0) {
+                // both rows of the lane as packed pairs: one v_pk_* instruction per operation
+                f2 cd, cr, cg, cb, ca0, ca1;
+                {
+                    const int c0 = (trow + r) * LW + col + r, c1 = c0 + LW;
+                    const float4 a0 = featA[c0], a1 = featA[c1];
+                    const float2 b0 = featB[c0], b1 = featB[c1];
+                    cd = f2{a0.x, a1.x}; cr = f2{a0.y, a1.y}; cg = f2{a0.z, a1.z}; cb = f2{a0.w, a1.w};
+                    ca0 = f2{b0.x, b1.x}; ca1 = f2{b0.y, b1.y};
+                }
+                const f2 tiny = f2{1e-30f, 1e-30f};
+                // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i
+                for (int jr = 0; jr < 2 + 2 * r; ++jr) {
+                    const int rowbase = (trow + jr) * LW + col;       // window column dx = -r (LDS offsets are unsigned)
+                    // one opaque LDS index per plane, so that every read of the row is base register + immediate
+                    int iQ0 = rowbase, iQ1 = rowbase + plane4, iA = rowbase + 2 * plane4, iB = rowbase + 6 * plane4;
+                    asm volatile("" : "+v"(iQ0), "+v"(iQ1), "+v"(iA), "+v"(iB));
+                    const float4 *rowQ0 = lds4 + iQ0, *rowQ1 = lds4 + iQ1, *rowA = lds4 + iA;
+                    const float2 *rowB = reinterpret_cast<const float2 *>(lds4) + iB;
+                    const float m0 = jr <= 2 * r ? 1.0f : 0.0f;      // row 0: dy = jr - r      in [-r, r]
+                    const float m1 = jr >= 1 ? 1.0f : 0.0f;          // row 1: dy = jr - r - 1  in [-r, r]
+                    const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : 0) * kw + r;          // weights of row 0's dy
+                    const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : 0) * kw + r;          // ... and of row 1's
+#pragma unroll
+                    for (int dx = -r; dx <= r; ++dx) {
+                        const float4 fa = rowA[dx + r];
+                        const float2 fb = rowB[dx + r];
+                        const float4 q0 = rowQ0[dx + r], q1 = rowQ1[dx + r];
+                        const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
+                        f2 mk = f2{m0, m1};
+                        if (dx == 0) mk = f2{jr == r ? 0.0f : m0, jr == r + 1 ? 0.0f : m1};      // centre excluded
+                        const f2 dj = f2{fa.x, fa.x};
+                        const f2 den = __builtin_elementwise_max(cd + dj, tiny);                // both depths 0 -> t = 0
+                        const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                        const f2 t = (dj - cd) * inv;
+                        const f2 u = t * t;
+                        const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
+                        const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
+                        const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
+                        const f2 ea = __builtin_elementwise_fma(g1, g1, g0 * g0);
+                        const f2 x1 = f2{K.K1, K.K1} * u;
+                        const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
+                        const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
+                        const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
+                        const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
+                        const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
+                        f2 sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
+                                __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
+                                __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{K.bias, K.bias})));
+                        sv = sv * mk;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float sI = i == 0 ? sv.x : sv.y;
+                            acc[ch][i][0] = fmaf(sI, q0.x, acc[ch][i][0]);
+                            acc[ch][i][1] = fmaf(sI, q0.y, acc[ch][i][1]);
+                            acc[ch][i][2] = fmaf(sI, q0.z, acc[ch][i][2]);
+                            acc[ch][i][3] = fmaf(sI, q0.w, acc[ch][i][3]);
+                            acc[ch][i][4] = fmaf(sI, q1.x, acc[ch][i][4]);
+                            acc[ch][i][5] = fmaf(sI, q1.y, acc[ch][i][5]);
+                            acc[ch][i][6] = fmaf(sI, q1.z, acc[ch][i][6]);
+                            acc[ch][i][7] = fmaf(sI, q1.w, acc[ch][i][7]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!ok[i]) continue;
+        float m[NCH * CH];
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
+        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], p[i], !valid[i], weight, last);
+    }
+}
+
+// depth u16 / rgb u8 / angles -> the float records the fused update stages: (d, r, g, b) and (a0, a1)
+__global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ rgb,
+                                                                const float *__restrict__ angles, float4 *__restrict__ featA,
+                                                                float2 *__restrict__ featB, size_t total)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    featA[q] = make_float4((float)depth[q], (float)rgb[3 * q], (float)rgb[3 * q + 1], (float)rgb[3 * q + 2]);
+    featB[q] = reinterpret_cast<const float2 *>(angles)[q];
 }
 
 template <int R, int PY, int NCH>
@@ -479,6 +757,24 @@ hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &
     const size_t lds = (size_t)2 * (ITW + 2 * g.r) * (ITH + 2 * g.r) * sizeof(float4);
     dim3 grid((g.ow + ITW - 1) / ITW, (g.oh + ITH - 1) / ITH, nframes);
     hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, last);
+    return hipGetLastError();
+}
+
+template <int R, int TH, int NCH>
+hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
+                          float weight, int first, int last, hipStream_t st)
+{
+    static bool attr_set = false;
+    auto kern = crf_iter_fused_kernel<R, TH, NCH>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
+    if (lds > 158 * 1024) return hipErrorInvalidValue;
+    dim3 grid((g.Wi + FTW - 1) / FTW, (g.Hi + TH - 1) / TH, nframes);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last);
     return hipGetLastError();
 }
 
@@ -530,12 +826,63 @@ void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hi
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3((unsigned)((P * S + 255) / 256)), dim3(256), 0, st, planes, rows, (int)P, S);
 }
 
-void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int grow, int32_t *recs, int32_t *max_active,
-                            hipStream_t st)
+void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
+                            int32_t *max_active, hipStream_t st)
 {
-    int tx, ty;
-    crf_tile_grid(H, W, &tx, &ty);
-    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, grow, recs, max_active);
+    const int tx = (W + tile_w - 1) / tile_w, ty = (H + tile_h - 1) / tile_h;
+    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, tile_w, tile_h, grow, recs, max_active);
+}
+
+// tile height of the fused kernel for a window radius: 16 rows while the staged tile fits in LDS, else 8
+int crf_fused_tile_height(int r)
+{
+    auto bytes = [&](int th) { return (size_t)(FTW + 2 * r) * (th + 2 * r) * (3 * sizeof(float4) + sizeof(float2)); };
+    if (bytes(16) <= 158 * 1024) return 16;
+    if (bytes(8) <= 158 * 1024) return 8;
+    return 0;
+}
+void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)
+{
+    const int th = crf_fused_tile_height(r);
+    *tiles_x = (W + FTW - 1) / FTW;
+    *tiles_y = th ? (H + th - 1) / th : 0;
+}
+
+void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
+                              size_t total, hipStream_t st)
+{
+    hipLaunchKernelGGL(crf_pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, depth, rgb, angles,
+                       reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total);
+}
+
+hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
+                                 const CrfParams &P, const float *wtab, int mode, hipStream_t st)
+{
+    if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
+    const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
+    const double l2e = 1.4426950408889634;
+    // delta_d = 12 t with t = (dq-dp)/(dp+dq); colour differences scaled by 1/50, angles by 2 (find_surfaces.py:20, 343-349)
+    FusedConsts K;
+    K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
+    K.C2 = (float)(P.t23 / 2500.0 * l2e); K.C3 = (float)(4.0 * P.t33 * l2e);
+    K.bias = P.bias;
+    const float4 *wt = reinterpret_cast<const float4 *>(wtab);
+    const int th = crf_fused_tile_height(g.r);
+#define FS_FUSED_CASES(RR, THH)                                                                              \
+    switch (channel_class) {                                                                                 \
+    case 1: return launch_fused_t<RR, THH, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 2: return launch_fused_t<RR, THH, 2>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 3:                                                                                                  \
+    case 4: return launch_fused_t<RR, THH, 4>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 8: return launch_fused_t<RR, THH, 8>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 16: return launch_fused_t<RR, THH, 16>(descs, nframes, g, K, wt, P.weight, first, last, st);       \
+    default: return hipErrorInvalidValue;                                                                    \
+    }
+    if (g.r == 7) { FS_FUSED_CASES(7, 16) }
+    if (th == 16) { FS_FUSED_CASES(0, 16) }
+    if (th == 8) { FS_FUSED_CASES(0, 8) }
+#undef FS_FUSED_CASES
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
