@@ -30,7 +30,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector (packed FMA), 256 CUs x 128 lanes x 2 x 2.4 GHz
 
 
 def load_frames(workload, count, rank):
@@ -151,17 +152,32 @@ def main():
         }
         if not args.no_kernel_timing:
             ms, launches = ctx.get_timing(ITER)
-            # (each timed interval is one mean-field update of a group of up to 16 frames)
-            # algorithmic bytes of one mean-field update of one frame: 24 B features + 4 B patch
-            # label + 4S read Q + 4S write Q per pixel; the last update writes an int64 label
-            # instead of Q.  Three updates per frame.
+            # Unit of the roofline figures: one mean-field update of one frame (launches are batched
+            # over up to 16 frames and split by channel class, so the per-frame update is the stable unit).
+            # Algorithmic bytes of one update of one frame: 24 B features + 4 B patch label + 4S read Q +
+            # 4S write Q per pixel; the last update writes an int64 label instead of Q.  Three updates per frame.
             per_frame = N * ((28 + 8 * S) * 2 + (28 + 4 * S + 8))
+            updates = 3 * n * args.steps
             total_bytes = float(per_frame.sum()) * args.steps
             achieved = total_bytes / (ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "crf_iter_kernel (mean-field update)", "achieved": achieved,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "avg_us_per_frame_update": 1e3 * ms / (3 * n * args.steps), "timed_intervals": int(launches),
-                               "share_of_step_time": ms * 1e-3 / dt}
+            # arithmetic the update needs: 224 neighbours x (about 45 flop similarity + 2S flop message) per pixel
+            kk = (2 * args.kernel_size + 1) ** 2 - 1
+            flops = float((N * kk * (45 + 2 * S)).sum()) * 3 * args.steps
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tpath) and args.workload == "osd" and args.kernel_size == 7:
+                with open(tpath) as f:
+                    traffic = json.load(f)["hbm_bytes_per_frame_update"]
+            out["roofline"] = {"bound": "hbm", "kernel": "crf_iter_fused_kernel (mean-field update, similarity evaluated in the kernel)",
+                               "per": "one mean-field update of one frame",
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": traffic,
+                               "algorithmic_bytes": total_bytes / updates,
+                               "avg_us": 1e3 * ms / updates, "timed_intervals": int(launches),
+                               "share_of_step_time": ms * 1e-3 / dt,
+                               "valu": {"achieved": flops / (ms * 1e-3) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                                        "note": "algorithmic fp32 flops; the kernel is bound by vector ALU issue, not HBM"}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(depth, rgb)
         print(json.dumps(out), flush=True)
