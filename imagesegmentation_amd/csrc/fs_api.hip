@@ -296,6 +296,9 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             order[k] = k;
             int ce = fused ? max_active[g0 + k] + 3 : S[g0 + k];   // without per-tile lists every label is carried
             if (ce > S[g0 + k]) ce = S[g0 + k];
+            if (ce > kMaxTileChannels)
+                return ctx->fail("a tile of frame " + std::to_string(g0 + k) + " needs " + std::to_string(ce) + " label channels; at most " +
+                                 std::to_string(kMaxTileChannels) + " are supported");
             cls[k] = crf_channel_class(ce);
             qoff[k] = q;
             q += (size_t)S[g0 + k] * N;
@@ -550,7 +553,8 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
     if (!ctx) return -1;
     if (set_device(ctx)) return -1;
     if (!ctx->have_params) return ctx->fail("fs_crf_step: call fs_set_gauss_params first");
-    if (B < 1 || h < 1 || w < 1 || S < 2 || S > kMaxLabels) return ctx->fail("fs_crf_step: bad shape");
+    if (B < 1 || h < 1 || w < 1 || S < 2) return ctx->fail("fs_crf_step: bad shape");
+    if (S > kMaxTileChannels) return ctx->fail("fs_crf_step: at most " + std::to_string(kMaxTileChannels) + " label channels");
     for (int l = 0; l < S; ++l)
         if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step: val must be the one-hot of the last label");
     const int r = ctx->r, hp = h + 2 * r, wp = w + 2 * r;

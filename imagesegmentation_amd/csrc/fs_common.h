@@ -34,7 +34,8 @@ struct CrfParams {
     float weight;
 };
 
-constexpr int kMaxLabels = 128;   // label channels S = num_surfaces + 1 supported by the CRF kernels
+constexpr int kMaxLabels = 512;       // label channels S = num_surfaces + 1 of a frame (multiple of 32)
+constexpr int kMaxTileChannels = 128; // channels one tile can carry: listed labels + 3; also the limit of fs_crf_step
 constexpr int kMaxRadius = 15;    // largest CRF window radius (kernel_size)
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----

@@ -203,22 +203,25 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const float *__rest
 
 // ---------------------------------------------------------------------------
 // per-tile list of the patch labels present within `grow` pixels of the tile.
-// record (TILE_REC ints): [0] = count A, [4..7] = bit mask, [8..8+A) = labels
+// record (TILE_REC ints): [0] = count A, [REC_MASK .. REC_MASK+MASK_WORDS) = bit mask,
+// [REC_LAB .. REC_LAB+A) = labels
 // ascending.  max_active[frame] receives the largest A of the frame.
 // ---------------------------------------------------------------------------
 constexpr int ITW = 64, ITH = 16;             // tile of the update kernel
-constexpr int TILE_REC = kMaxLabels + 8;
+constexpr int MASK_WORDS = kMaxLabels / 32;
+constexpr int REC_MASK = 8, REC_LAB = REC_MASK + MASK_WORDS;
+constexpr int TILE_REC = REC_LAB + kMaxLabels;
 
 __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tw, int th,
                                                               int grow, int32_t *__restrict__ recs,
                                                               int32_t *__restrict__ max_active)
 {
-    __shared__ unsigned mask[4];
+    __shared__ unsigned mask[MASK_WORDS];
     const int frame = blockIdx.z;
     const int32_t *P = patches + (size_t)frame * H * W;
     const int tiles_x = gridDim.x, tiles_y = gridDim.y;
     int32_t *rec = recs + ((size_t)frame * tiles_x * tiles_y + (size_t)blockIdx.y * tiles_x + blockIdx.x) * TILE_REC;
-    if (threadIdx.x < 4) mask[threadIdx.x] = 0u;
+    if (threadIdx.x < MASK_WORDS) mask[threadIdx.x] = 0u;
     __syncthreads();
     const int xa = max(0, (int)blockIdx.x * tw - grow), xb = min(W, (int)(blockIdx.x + 1) * tw + grow);
     const int ya = max(0, (int)blockIdx.y * th - grow), yb = min(H, (int)(blockIdx.y + 1) * th + grow);
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         int A = 0;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < MASK_WORDS; ++w) {
             unsigned m = mask[w];
-            rec[4 + w] = (int32_t)m;
+            rec[REC_MASK + w] = (int32_t)m;
             while (m) {
                 const int b = __ffs(m) - 1;
-                rec[8 + A++] = w * 32 + b;
+                rec[REC_LAB + A++] = w * 32 + b;
                 m &= m - 1;
             }
         }
@@ -252,41 +255,41 @@ __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__r
 // ---------------------------------------------------------------------------
 // one mean-field update: shared pieces
 // ---------------------------------------------------------------------------
-// Channel list of a tile in LDS: s_list[0]=CE, [1]=n_rest, [2]=rep_pos, [4..7]=bit mask of the
-// listed labels (without the representative), [8..8+CE) = labels [0, listed..., representative, S-1].
+// Channel list of a tile in LDS: s_list[0]=CE, [1]=n_rest, [2]=rep_pos, [REC_MASK..)=bit mask of the
+// listed labels (without the representative), [REC_LAB..REC_LAB+CE) = labels [0, listed..., representative, S-1].
 template <int NT>
 __device__ __forceinline__ void build_channel_list(int *s_list, const int32_t *tile_recs, int tile, int S)
 {
     const int tid = threadIdx.x;
     if (tile_recs) {
         const int32_t *rec = tile_recs + (size_t)tile * TILE_REC;
-        for (int t = tid; t < TILE_REC; t += NT) s_list[t] = rec[t];
+        const int used = REC_LAB + rec[0];
+        for (int t = tid; t < used; t += NT) s_list[t] = rec[t];
         __syncthreads();
         if (tid == 0) {
             const int A = s_list[0];
-            unsigned m[4] = {(unsigned)s_list[4], (unsigned)s_list[5], (unsigned)s_list[6], (unsigned)s_list[7]};
-            for (int i = A - 1; i >= 0; --i) s_list[9 + i] = s_list[8 + i];
-            s_list[8] = 0;
+            int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
+            for (int i = A - 1; i >= 0; --i) labs[1 + i] = labs[i];
+            labs[0] = 0;
             int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
             if (n_rest > 0) {
                 int rep = 1;
-                while (m[rep >> 5] >> (rep & 31) & 1u) ++rep;   // smallest unlisted label in [1, S-2]
+                while ((unsigned)m[rep >> 5] >> (rep & 31) & 1u) ++rep;   // smallest unlisted label in [1, S-2]
                 rep_pos = ce;
-                s_list[8 + ce++] = rep;
+                labs[ce++] = rep;
             }
-            s_list[8 + ce++] = S - 1;
-            m[0] |= 1u;
-            m[(S - 1) >> 5] |= 1u << ((S - 1) & 31);
+            labs[ce++] = S - 1;
+            m[0] |= 1;
+            m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
             s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
-            s_list[4] = (int)m[0]; s_list[5] = (int)m[1]; s_list[6] = (int)m[2]; s_list[7] = (int)m[3];
         }
     } else {
-        for (int t = tid; t < S; t += NT) s_list[8 + t] = t;
+        for (int t = tid; t < S; t += NT) s_list[REC_LAB + t] = t;
         if (tid == 0) { s_list[0] = S; s_list[1] = 0; s_list[2] = -1; }
-        if (tid < 4) {
+        if (tid < MASK_WORDS) {
             const int lo = tid * 32;
             unsigned m = S >= lo + 32 ? 0xffffffffu : (S > lo ? (1u << (S - lo)) - 1u : 0u);
-            s_list[4 + tid] = (int)m;
+            s_list[REC_MASK + tid] = (int)m;
         }
     }
     __syncthreads();
@@ -301,7 +304,7 @@ __device__ __forceinline__ void stage_q(float4 *lds4, const int *s_list, const f
     const int plane4 = LH * LW;
     int labs[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) labs[k] = c0 + k < CE ? s_list[8 + c0 + k] : -1;
+    for (int k = 0; k < 8; ++k) labs[k] = c0 + k < CE ? s_list[REC_LAB + c0 + k] : -1;
     for (int ly = wv; ly < LH; ly += NW) {
         const int gy = iy0 - r + ly;
         const bool rowin = gy >= 0 && gy < Hi;
@@ -346,7 +349,7 @@ __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < CE) {
-            const int lab = s_list[8 + c];
+            const int lab = s_list[REC_LAB + c];
             const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
             float un;
             if (d.unary) un = d.unary[(size_t)lab * No + wi];
@@ -372,7 +375,7 @@ __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < CE) {
-            const int lab = s_list[8 + c];
+            const int lab = s_list[REC_LAB + c];
             float q = m[c] / den;
             if (invalid) q = last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
             if (c == rep_pos && !COMPACT) q_rep = q;                 // written with the other unlisted labels below
@@ -383,7 +386,7 @@ __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, 
     if (!COMPACT && n_rest > 0 && (d.Qout || d.potentials)) {
         // every unlisted label carries the representative's value
         for (int l = 1; l < S - 1; ++l) {
-            if ((unsigned)s_list[4 + (l >> 5)] >> (l & 31) & 1u) continue;
+            if ((unsigned)s_list[REC_MASK + (l >> 5)] >> (l & 31) & 1u) continue;
             if (d.Qout) d.Qout[(size_t)l * No + wi] = q_rep;
             if (d.potentials) d.potentials[(size_t)l * No + wi] = add_rep;
         }
@@ -558,12 +561,12 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
             for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
         } else {
             const int32_t *rec = d.tile_recs + ((size_t)sy * tiles_x + sx) * TILE_REC;
-            const unsigned m[4] = {(unsigned)rec[4], (unsigned)rec[5], (unsigned)rec[6], (unsigned)rec[7]};
+            const int32_t *m = rec + REC_MASK;
             int rep = 1;                                            // representative of the source tile
-            while (rep < S - 1 && (m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
+            while (rep < S - 1 && ((unsigned)m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
             for (int c = 0; c < CE; ++c) {
-                const int l = s_list[8 + c];
-                const bool listed = l == 0 || l == S - 1 || (m[l >> 5] >> (l & 31) & 1u);
+                const int l = s_list[REC_LAB + c];
+                const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
                 s_src[tid][c] = listed ? l : rep;
             }
         }
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
                         const int lab = in ? d.patches[q] : -1;
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
-                            const int l = ch * CH + k < CE ? s_list[8 + ch * CH + k] : -1;
+                            const int l = ch * CH + k < CE ? s_list[REC_LAB + ch * CH + k] : -1;
                             float x = 0.0f;
                             if (lab >= 0 && l > 0) x = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
                             v[k] = x;
@@ -747,14 +750,15 @@ __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *
 template <int R, int PY, int NCH>
 hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, int last, hipStream_t st)
 {
-    static bool attr_set = false;
+    static size_t attr_lds = 0;
     auto kern = crf_iter_kernel<R, PY, NCH>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     const size_t lds = (size_t)2 * (ITW + 2 * g.r) * (ITH + 2 * g.r) * sizeof(float4);
+    if (lds + sizeof(int) * TILE_REC > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
     dim3 grid((g.ow + ITW - 1) / ITW, (g.oh + ITH - 1) / ITH, nframes);
     hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, last);
     return hipGetLastError();
@@ -764,15 +768,16 @@ template <int R, int TH, int NCH>
 hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
                           float weight, int first, int last, hipStream_t st)
 {
-    static bool attr_set = false;
+    static size_t attr_lds = 0;                  // dynamic LDS the kernel has been allowed so far
     auto kern = crf_iter_fused_kernel<R, TH, NCH>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
-    if (lds > 158 * 1024) return hipErrorInvalidValue;
+    const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8);
+    if (lds + lds_static > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
     dim3 grid((g.Wi + FTW - 1) / FTW, (g.Hi + TH - 1) / TH, nframes);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last);
     return hipGetLastError();
@@ -837,8 +842,8 @@ void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int til
 int crf_fused_tile_height(int r)
 {
     auto bytes = [&](int th) { return (size_t)(FTW + 2 * r) * (th + 2 * r) * (3 * sizeof(float4) + sizeof(float2)); };
-    if (bytes(16) <= 158 * 1024) return 16;
-    if (bytes(8) <= 158 * 1024) return 8;
+    if (bytes(16) <= 150 * 1024) return 16;
+    if (bytes(8) <= 150 * 1024) return 8;
     return 0;
 }
 void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)

@@ -1,0 +1,178 @@
+"""CPU tests of the host-side mirror (no GPU, no compute through the library): tiling glue,
+potentials/initial probabilities, loaders, the out/{index}/*.npy layout, sharding and the
+C ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+# ------------------------------------------------------------------- tiling glue
+def test_get_inputs_and_assemble_outputs_round_trip():
+    from imagesegmentation_amd import find_surfaces as fs
+    rng = np.random.default_rng(0)
+    H, W, S, r = 24, 32, 5, 3
+    feats = [rng.random((H, W, c)) for c in (3, 6, 5)]
+    unary, Q = rng.random((H, W, S)), rng.random((H, W, S))
+    inputs = fs.get_inputs(feats, unary, Q, r, 4, 4, W // 4, H // 4)
+    un, Qin, f1, f2, f3, val = inputs
+    assert un.shape == (16, 6, 8, S) and Qin.shape == (16, 6 + 2 * r, 8 + 2 * r, S)
+    assert f1.shape[-1] == 3 and f2.shape[-1] == 6 and f3.shape[-1] == 5
+    assert val.shape == (16, 1, 1, 1, S) and (val[..., -1] == 1).all() and val.sum() == 16
+    # tile 1 is the second tile down the first column (x outer, y inner)
+    assert np.array_equal(un[1], unary[6:12, 0:8])
+    # halo of the first tile is zero padding
+    assert (Qin[0][:r] == 0).all() and (Qin[0][:, :r] == 0).all()
+    assert np.array_equal(Qin[0][r:, r:], Q[:6 + r, :8 + r])
+    # cutting the unpadded centre of every tile and stitching gives the frame back
+    back = fs.assemble_outputs(Qin[:, r:-r, r:-r], 4, 4, W // 4, H // 4, H, W)
+    assert np.array_equal(back, Q)
+
+
+def test_host_glue_agrees_with_oracle_glue():
+    from imagesegmentation_amd import find_surfaces as fs
+    from oracle import oracle_np as N
+    rng = np.random.default_rng(1)
+    H, W, r = 16, 24, 2
+    patches = rng.integers(0, 4, (H, W))
+    ns = int(patches.max()) + 1
+    u1, q1, p1 = fs.get_unary_potentials_and_initial_probabilities({"patches": patches, "num_surfaces": ns})
+    u2, q2, p2 = N.get_unary_potentials_and_initial_probabilities(patches, ns)
+    assert np.array_equal(u1, u2) and np.array_equal(q1, q2) and np.array_equal(p1, p2)
+    feats = [rng.random((H, W, c)) for c in (3, 6, 5)]
+    a = fs.get_inputs(feats, u1, q1, r, 2, 2, W // 2, H // 2)
+    b = N.get_inputs(feats, u2, q2, r, 2, 2, W // 2, H // 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_unary_known_answer():
+    from imagesegmentation_amd import find_surfaces as fs
+    d = {"patches": np.array([[0, 2], [1, 0]]), "num_surfaces": 3}
+    unary, q0, prob = fs.get_unary_potentials_and_initial_probabilities(d)
+    assert unary.dtype == np.float64 and unary.shape == (2, 2, 4) and prob.shape == (1, 1, 4)
+    assert np.array_equal(unary[0, 1], [10, 1, 0, 1]) and np.array_equal(unary[0, 0], [10, 1, 1, 1])
+    assert np.allclose(q0[1, 0], [0, 0.9, 0.05, 0.05]) and np.allclose(q0[1, 1], [0, 1 / 3, 1 / 3, 1 / 3])
+
+
+def test_extract_features_layout():
+    from imagesegmentation_amd import find_surfaces as fs
+    H, W = 4, 6
+    grid = fs._grid(H, W)
+    assert grid[2, 5, 0] == 2 and grid[2, 5, 1] == 5
+    depth = np.arange(H * W).reshape(H, W)
+    f1, f2, f3 = fs.extract_features(depth, np.ones((H, W, 3)), np.zeros((H, W, 2)), grid)
+    assert f1.shape == (H, W, 3) and f2.shape == (H, W, 6) and f3.shape == (H, W, 5)
+    assert f1[3, 4, 2] == depth[3, 4] and f2[0, 0, 3] == 1
+
+
+def test_load_gauss_parameters_shape():
+    from imagesegmentation_amd import find_surfaces as fs
+    p = fs.load_Gauss_parameters()
+    assert len(p) == 13 and all(v.shape == (1, 1) for v in p)
+    assert p[3][0, 0] == 0 and abs(p[12][0, 0] - 0.01) < 1e-9
+    crf = fs.conv_crf_Gauss(*p, 7, 120, 160)
+    assert crf.params.shape == (13,) and crf.kernel_size == 7
+    with pytest.raises(NotImplementedError):
+        fs.get_GPU_models("LR")
+
+
+# ------------------------------------------------------------------- loaders and file layout
+def test_sorted_alphanumeric_and_load_image():
+    from imagesegmentation_amd import load_images as li
+    assert li.sorted_alphanumeric(["10.png", "9.png", "0.png", "100.png"]) == ["0.png", "9.png", "10.png", "100.png"]
+    depth, rgb, ann = li.load_image(3)
+    assert depth.shape == (480, 640) and depth.dtype == np.uint16
+    assert rgb.shape == (480, 640, 3) and rgb.dtype == np.uint8 and ann.shape == (480, 640)
+
+
+def test_npy_layout_round_trip(tmp_path, monkeypatch):
+    from imagesegmentation_amd import load_images as li
+    monkeypatch.setattr(li, "out_root", str(tmp_path / "out"))
+    depth, rgb, ann = li.load_image(0)
+    rng = np.random.default_rng(2)
+    data = {"depth": depth, "rgb": rgb, "annotation": ann,
+            "angles": rng.random((480, 640, 2), np.float32), "vectors": rng.random((480, 640, 3), np.float32),
+            "points_3d": rng.random((480, 640, 3), np.float32), "patches": rng.integers(0, 5, (480, 640)),
+            "depth_edges": rng.integers(0, 2, (480, 640)).astype(np.int32), "surfaces": rng.integers(0, 7, (480, 640))}
+    li.save_surface_information(0, data)
+    files = sorted(os.listdir(tmp_path / "out" / "0"))
+    assert files == ["Q.npy", "angles.npy", "depth.npy", "edges.npy", "patches.npy", "points.npy", "vectors.npy"]
+    back = li.load_image_and_surface_information(0)
+    for k in ("angles", "vectors", "points_3d", "patches", "depth_edges", "surfaces", "depth"):
+        assert np.array_equal(back[k], data[k]) and back[k].dtype == data[k].dtype, k
+    assert back["num_surfaces"] == int(data["surfaces"].max()) + 1
+    assert back["lab"].shape == (480, 640, 3)
+    with pytest.raises(SystemExit):
+        li.load_image_and_surface_information(1)       # nothing saved for index 1
+
+
+def test_rgb_to_lab_known_colours():
+    from imagesegmentation_amd.utils import rgb_to_Lab
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 0, 255]]], np.uint8)
+    lab = rgb_to_Lab(px)[0]
+    assert np.allclose(lab[0], [100, 0, 0], atol=0.02) and np.allclose(lab[1], [0, 0, 0], atol=1e-9)
+    assert np.allclose(lab[2], [53.24, 80.09, 67.20], atol=0.02)      # CIE L*a*b* of sRGB red under D65
+    assert np.allclose(lab[3], [32.30, 79.19, -107.86], atol=0.02)    # ... and of sRGB blue
+
+
+def test_angles_to_normals():
+    from imagesegmentation_amd.utils import angles_to_normals
+    n = angles_to_normals(np.array([[0.0, 0.0], [np.pi / 2, 0.0], [0.0, np.pi / 2]]))
+    assert np.allclose(n, [[0, 0, -1], [0, 1, 0], [-1, 0, 0]], atol=1e-12)
+
+
+# ------------------------------------------------------------------- sharding
+def test_shard_is_a_partition():
+    from imagesegmentation_amd.sharding import shard
+    idx = list(range(111))
+    for world in (1, 2, 4, 8):
+        parts = [shard(idx, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == idx
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+        assert all(i % world == r for r, p in enumerate(parts) for i in p)
+    with pytest.raises(ValueError):
+        shard(idx, 2, 2)
+
+
+# ------------------------------------------------------------------- C ABI surface
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "fs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"\b(fs_[a-z_]+)\s*\(", src)
+
+
+def test_library_exports_every_declared_symbol():
+    from imagesegmentation_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 18 and len(set(names)) == len(names)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fs_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes prototypes and header disagree"
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a usable GPU the library must refuse to create a context (and say why)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from imagesegmentation_amd import _lib
+    with pytest.raises(RuntimeError):
+        _lib.Context(480, 640)
+    from imagesegmentation_amd import find_surfaces as fs
+    with pytest.raises(RuntimeError):
+        fs.find_surface_model("Gauss")((np.zeros((480, 640), np.uint16), np.zeros((480, 640, 3), np.uint8), None))
+
+
+def test_product_code_does_not_touch_the_oracle():
+    """Only tests, smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "imagesegmentation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), f"{os.path.join(dirpath, f)} mentions the oracle"
