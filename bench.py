@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--kernel-size", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="time the host-pointer entry point instead (inputs and the 6 output arrays cross PCIe); "
+                         "a side measurement, not the headline value")
     args = ap.parse_args()
 
     import torch
@@ -112,6 +115,8 @@ def main():
     d_surfaces = torch.empty((n, H, W), dtype=torch.int64, device=dev)
 
     def step():
+        if args.host_buffers:
+            return ctx.find_surfaces_batch(depth, rgb)["num_surfaces"]
         return ctx.find_surfaces_batch_dev(n, d_depth.data_ptr(), d_rgb.data_ptr(), d_angles.data_ptr(), d_vectors.data_ptr(),
                                            d_points.data_ptr(), d_patches.data_ptr(), d_edges.data_ptr(), d_surfaces.data_ptr())
 
@@ -145,7 +150,8 @@ def main():
             "metric": "find_surfaces images/sec @640x480" if (H, W) == (480, 640) else f"find_surfaces images/sec @{W}x{H}",
             "value": world * n * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": data_desc,
+            "vs_baseline": None, "dtype": "f32",
+            "data": data_desc + (" (host buffers: PCIe copies inside the timed region)" if args.host_buffers else ""),
             "config": {"workload": f"find_surfaces, {n} frames/step/GPU, {W}x{H}, kernel_size {args.kernel_size}, 3 mean-field iterations",
                        "label_channels_min_median_max": [int(S.min()), int(np.median(S)), int(S.max())],
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
