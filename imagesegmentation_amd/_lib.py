@@ -36,6 +36,7 @@ SIGNATURES = {
     "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
     "fs_set_timing": (_i, [_vp, _i]),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
 }
@@ -239,6 +240,34 @@ class Context:
         self._check(self._lib.fs_find_surfaces_batch_dev(self._h, n, d_depth, d_rgb, d_angles, d_vectors, d_points,
                                                          d_patches, d_edges, d_surfaces, _ptr(ns)))
         return ns
+
+    def surface_stats(self, surfaces, patches, depth_edges, points_3d, angles, lab, texture, num_surfaces):
+        """fs_surface_stats for one frame -> dict of arrays (see include/fs_hip.h)."""
+        S, H, W = int(num_surfaces), self.H, self.W
+        surfaces, patches = _arr(surfaces, np.int64, (H, W)), _arr(patches, np.int64, (H, W))
+        depth_edges = _arr(depth_edges, np.int32, (H, W))
+        points_3d, angles = _arr(points_3d, np.float32, (H, W, 3)), _arr(angles, np.float32, (H, W, 2))
+        lab = _arr(lab, np.float64, (H, W, 3))
+        T = 256
+        if texture is not None:
+            texture = _arr(texture, np.float32)
+            if texture.shape[:2] != (H // 4, W // 4):
+                raise ValueError(f"texture must be [{H // 4},{W // 4},T], got {texture.shape}")
+            T = texture.shape[2]
+        out = {
+            "surfaces": np.empty((H, W), np.int64), "patch_point_offsets": np.empty(S + 1, np.int32),
+            "patch_points": np.empty((H * W, 2), np.float32), "avg_pos": np.empty((S, 2)), "counts": np.empty((S, 1)),
+            "centroids": np.empty((S, 3), np.float32), "centroid_indices": np.empty((S, 2), np.int32),
+            "hist_color": np.empty((256, 256, S)), "hist_angle": np.empty((40, 40, S)), "hist_texture": np.empty((S, T)),
+            "avg_angles": np.empty((S, 2)), "neighbor_counts": np.empty((S, S)), "border_centers": np.empty((S, S, 2)),
+            "norm": np.empty((H, W), np.float32), "depth_extend": np.empty((S, 4, 2), np.float32),
+        }
+        order = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+                 "hist_color", "hist_angle", "hist_texture", "avg_angles", "neighbor_counts", "border_centers", "norm",
+                 "depth_extend")
+        self._check(self._lib.fs_surface_stats(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
+                                               _ptr(angles), _ptr(lab), _ptr(texture), T, *(_ptr(out[k]) for k in order)))
+        return out
 
     def apply_crf(self, labels, depth, rgb, angles):
         lab, single = self._batch(labels)

@@ -60,6 +60,41 @@ struct CcWork {
 size_t cc_blocks_per_image(int H, int W);
 void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_size_exclusive, int64_t *labels64,
                                  int32_t *labels32, int n, int H, int W, hipStream_t st);
+// components of a label image (equal non-zero values, 4-connectivity): parent[p] = flat index of the first
+// pixel of p's component (-1 where the label is 0), count[root] = pixels of the component
+void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st);
+// per-surface statistics of one frame (k_stats.hip); every pointer is device memory
+struct StatsIn {
+    const int64_t *surfaces, *patches;   // [H][W]
+    const int32_t *depth_edges;          // [H][W]
+    const float *points_3d, *angles;     // [H][W][3], [H][W][2]
+    const double *lab;                   // [H][W][3]
+    const float *texture;                // [H/4][W/4][T] or null
+};
+struct StatsWork {
+    int32_t *surf32, *pat32, *parent, *count;                     // [N] each
+    uint32_t *sort_key, *sort_key_out, *sort_val, *sort_val_out;  // [N] each
+    void *sort_temp;
+    size_t sort_temp_bytes;
+    void *scratch;                                                // stats_work_bytes(S, T)
+};
+struct StatsOut {
+    int64_t *surfaces;                   // [H][W] relabelled, disconnected parts removed
+    int32_t *patch_point_offsets;        // [S+1]
+    float *patch_points;                 // [N][2] (x, y), grouped by patch label, raster order inside a label
+    double *avg_pos, *counts;            // [S][2], [S]
+    float *centroids;                    // [S][3]
+    int32_t *centroid_idx;               // [S][2] (y, x)
+    double *hist_color, *hist_angle, *hist_texture, *avg_angles;   // [256][256][S], [40][40][S], [S][T], [S][2]
+    uint32_t *nb_count;                  // [S][S] one-directional pair counts (row = the pixel, column = its lower/right neighbour)
+    unsigned long long *nb_sum;          // [S][S][2] sums of the doubled border coordinates
+    float *norm;                         // [H][W]
+    float *depth_extend;                 // [S][4][2]
+    int *err;                            // 0 ok, 1 label out of range, 2 colour bin out of range, 3 angle bin out of range
+};
+size_t stats_sort_temp_bytes(int N);
+size_t stats_work_bytes(int S, int T);
+hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const StatsOut &out, int H, int W, int S, int T, hipStream_t st);
 // CRF (k_crf.hip)
 struct CrfFrameDesc {            // one frame of a batched launch (device-resident array of these)
     const float *sim0;           // similarity plane 0 of the frame (slack lies in front of it)

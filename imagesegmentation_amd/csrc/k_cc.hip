@@ -66,17 +66,20 @@ __device__ __forceinline__ void uf_union(int32_t *L, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(CC_BLOCK) void cc_init_kernel(const uint8_t *__restrict__ mask, int32_t *__restrict__ parent,
+// T = uint8_t (binary mask) or int32_t (label image): pixels are connected when their values are
+// equal and non-zero.
+template <typename T>
+__global__ __launch_bounds__(CC_BLOCK) void cc_init_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
                                                            int32_t *__restrict__ count, int N, int W)
 {
     const size_t fo = (size_t)blockIdx.y * N;
     const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool in = p < N;
-    const int m = in ? mask[fo + p] : 0;
+    const int m = in ? (int)mask[fo + p] : 0;
     const int x = in ? p % W : 0;
     const int mprev = __shfl_up(m, 1);
-    const bool start = m && (lane == 0 || x == 0 || !mprev);
+    const bool start = m && (lane == 0 || x == 0 || mprev != m);
     const unsigned long long sb = __ballot(start);
     if (in) {
         int par = -1;
@@ -90,20 +93,22 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_init_kernel(const uint8_t *__rest
     }
 }
 
-__global__ __launch_bounds__(CC_BLOCK) void cc_merge_kernel(const uint8_t *__restrict__ mask, int32_t *__restrict__ parent,
+template <typename T>
+__global__ __launch_bounds__(CC_BLOCK) void cc_merge_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
                                                             int N, int W)
 {
     const size_t fo = (size_t)blockIdx.y * N;
     const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
     if (p >= N) return;
-    const uint8_t *M = mask + fo;
+    const T *M = mask + fo;
     int32_t *L = parent + fo;
-    if (!M[p]) return;
+    const T m = M[p];
+    if (!m) return;
     const int x = p % W;
-    const bool left = x > 0 && M[p - 1];
+    const bool left = x > 0 && M[p - 1] == m;
     if (left && (threadIdx.x & 63) == 0) uf_union(L, p, p - 1);   // run continues across the wave boundary
-    if (p >= W && M[p - W]) {
-        const bool covered = left && M[p - W - 1];                 // the left pixel makes the same vertical link
+    if (p >= W && M[p - W] == m) {
+        const bool covered = left && M[p - W - 1] == m;            // the left pixel makes the same vertical link
         if (!covered) uf_union(L, p, p - W);
     }
 }
@@ -228,13 +233,22 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const int N = H * W;
     const int nblk = (int)cc_blocks_per_image(H, W);
     const dim3 grid(nblk, n), block(CC_BLOCK);
-    hipLaunchKernelGGL(cc_init_kernel, grid, block, 0, st, mask, w.parent, w.count, N, W);
-    hipLaunchKernelGGL(cc_merge_kernel, grid, block, 0, st, mask, w.parent, N, W);
+    hipLaunchKernelGGL(cc_init_kernel<uint8_t>, grid, block, 0, st, mask, w.parent, w.count, N, W);
+    hipLaunchKernelGGL(cc_merge_kernel<uint8_t>, grid, block, 0, st, mask, w.parent, N, W);
     hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, w.parent, w.count, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
     hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_relabel_kernel, grid, block, 0, st, w.parent, w.newid, labels64, labels32, N);
+}
+
+void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st)
+{
+    const int N = H * W;
+    const dim3 grid((unsigned)cc_blocks_per_image(H, W), n), block(CC_BLOCK);
+    hipLaunchKernelGGL(cc_init_kernel<int32_t>, grid, block, 0, st, labels, parent, count, N, W);
+    hipLaunchKernelGGL(cc_merge_kernel<int32_t>, grid, block, 0, st, labels, parent, N, W);
+    hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, parent, count, N);
 }
 
 }  // namespace fs

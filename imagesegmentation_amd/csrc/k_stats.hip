@@ -1,0 +1,407 @@
+// Per-surface statistics of a labelled frame (gfx950): the pixel-level loops of
+// extract_information_from_surface_data_and_preprocess_surfaces (process_surfaces.py:672-687)
+//   extract_individual_points_from_surfaces            :96-108   stable sort of pixel indices by patch label
+//   relabel_surfaces                                   :236-242
+//   determine_pixel_counts_and_average_position_...    :111-129  integer sums, exact
+//   determine_surface_patch_centroids                  :81-93    first minimum of an fp64 distance
+//   remove_disconnected_components                     :8-28     label components instead of flood fills
+//   determine_histograms_and_average_normals           :245-297
+//   determine_neighboring_surfaces_and_border_centers  :31-59    (the S x S post-processing runs on the host)
+//   calculate_depth_extend                             :332-346
+// All of it is HBM-bound integer / byte work: one pass per dependency level, per-block
+// privatisation in LDS of everything indexed by label, one global atomic per (block, label).
+#include <algorithm>
+
+#include <hipcub/hipcub.hpp>
+
+#include "fs_common.h"
+
+namespace fs {
+
+namespace {
+
+constexpr int SB = 256;            // threads per block
+constexpr int SPB = 1024;          // pixels per block (4 per thread, interleaved for coalescing)
+
+__device__ __forceinline__ unsigned enc_f32(float f)      // order-preserving float -> unsigned
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// relabel, int32 working copies, interior counts and position sums, patch-pixel counts, sort input
+__global__ __launch_bounds__(SB) void stats_prepare_kernel(const int64_t *__restrict__ surfaces, const int64_t *__restrict__ patches,
+                                                           int32_t *__restrict__ surf32, int32_t *__restrict__ pat32,
+                                                           uint32_t *__restrict__ sort_key, uint32_t *__restrict__ sort_val,
+                                                           unsigned long long *__restrict__ acc, int *__restrict__ err, int H, int W, int S)
+{
+    extern __shared__ uint32_t sh[];             // [4][S]: interior count, sum x, sum y, patch count
+    const int N = H * W;
+    for (int i = threadIdx.x; i < 4 * S; i += SB) sh[i] = 0u;
+    __syncthreads();
+    for (int k = 0; k < SPB / SB; ++k) {
+        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+        if (p >= N) continue;
+        const int64_t pl = patches[p], sl = surfaces[p];
+        if (pl < 0 || pl >= S || sl < 0 || sl >= S) { *err = 1; continue; }   // every lane that writes stores the same value
+        const int s = pl != 0 ? (int)pl : (int)sl;
+        surf32[p] = s;
+        pat32[p] = (int)pl;
+        sort_key[p] = (uint32_t)pl;
+        sort_val[p] = (uint32_t)p;
+        atomicAdd(&sh[3 * S + (int)pl], 1u);
+        const int y = p / W, x = p - y * W;
+        if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+            atomicAdd(&sh[s], 1u);
+            atomicAdd(&sh[S + s], (uint32_t)x);
+            atomicAdd(&sh[2 * S + s], (uint32_t)y);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * S; i += SB)
+        if (sh[i]) atomicAdd(acc + i, (unsigned long long)sh[i]);
+}
+
+// one block: patch-point offsets (exclusive scan), counts and average positions
+__global__ __launch_bounds__(1024) void stats_offsets_kernel(const unsigned long long *__restrict__ acc, int32_t *__restrict__ offsets,
+                                                             double *__restrict__ avg_pos, double *__restrict__ counts, int S)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int v = t < S ? (int)acc[3 * S + t] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int u = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += u;
+        __syncthreads();
+    }
+    if (t < S) {
+        offsets[t] = part[t] - v;
+        if (t == S - 1) offsets[S] = part[t];
+        const double c = (double)acc[t];
+        counts[t] = c;
+        avg_pos[2 * t] = c > 0 ? (double)acc[S + t] / c : 0.0;
+        avg_pos[2 * t + 1] = c > 0 ? (double)acc[2 * S + t] / c : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(SB) void stats_points_kernel(const uint32_t *__restrict__ sorted_idx, float2 *__restrict__ points, int N, int W)
+{
+    const int k = blockIdx.x * SB + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t p = sorted_idx[k];
+    const uint32_t y = p / W;
+    points[k] = make_float2((float)(p - y * W), (float)y);
+}
+
+__device__ __forceinline__ unsigned long long dist_bits(int p, int W, const double *avg_pos, int l)
+{
+    const int y = p / W, x = p - y * W;
+    const double dx = (double)x - avg_pos[2 * l], dy = (double)y - avg_pos[2 * l + 1];
+    return (unsigned long long)__double_as_longlong(dx * dx + dy * dy);   // non-negative doubles order like their bit patterns
+}
+
+// pass 1: smallest squared distance per label; pass 2: smallest pixel index among the pixels that attain it
+template <int PASS>
+__global__ __launch_bounds__(SB) void stats_centroid_kernel(const int32_t *__restrict__ pat32, const double *__restrict__ avg_pos,
+                                                            unsigned long long *__restrict__ best, int N, int W, int S)
+{
+    extern __shared__ unsigned long long shb[];  // [S]
+    for (int i = threadIdx.x; i < S; i += SB) shb[i] = ~0ull;
+    __syncthreads();
+    for (int k = 0; k < SPB / SB; ++k) {
+        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+        if (p >= N) continue;
+        const int l = pat32[p];
+        const unsigned long long d = dist_bits(p, W, avg_pos, l);
+        if (PASS == 1) {
+            if (d < shb[l]) atomicMin(&shb[l], d);
+        } else if (d == best[l]) {
+            atomicMin(&shb[l], (unsigned long long)p);
+        }
+    }
+    __syncthreads();
+    unsigned long long *dst = PASS == 1 ? best : best + S;
+    for (int i = threadIdx.x; i < S; i += SB)
+        if (shb[i] != ~0ull) atomicMin(dst + i, shb[i]);
+}
+
+__global__ __launch_bounds__(SB) void stats_centroid_finish_kernel(const unsigned long long *__restrict__ best, const float *__restrict__ points_3d,
+                                                                   float *__restrict__ centroids, int32_t *__restrict__ centroid_idx,
+                                                                   int32_t *__restrict__ cpix, int W, int S)
+{
+    const int l = blockIdx.x * SB + threadIdx.x;
+    if (l >= S) return;
+    const unsigned long long b = best[S + l];
+    if (b == ~0ull) {
+        cpix[l] = -1;
+        centroid_idx[2 * l] = centroid_idx[2 * l + 1] = -1;
+        centroids[3 * l] = centroids[3 * l + 1] = centroids[3 * l + 2] = -1.0f;
+        return;
+    }
+    const int p = (int)b, y = p / W;
+    cpix[l] = p;
+    centroid_idx[2 * l] = y;
+    centroid_idx[2 * l + 1] = p - y * W;
+    for (int c = 0; c < 3; ++c) centroids[3 * l + c] = points_3d[3 * (size_t)p + c];
+}
+
+// keep a pixel iff it lies in the component of its label's centroid pixel (or is the start pixel of label 0's fill)
+__global__ __launch_bounds__(SB) void stats_keep_kernel(int32_t *__restrict__ surf32, const int32_t *__restrict__ parent,
+                                                        const int32_t *__restrict__ cpix, int64_t *__restrict__ surfaces_out, int N)
+{
+    const int p = blockIdx.x * SB + threadIdx.x;
+    if (p >= N) return;
+    const int s = surf32[p];
+    int keep = 0;
+    if (s != 0) {
+        const int c = cpix[s];
+        keep = (c >= 0 && parent[p] == parent[c]) || p == cpix[0];
+    }
+    const int out = keep ? s : 0;
+    surf32[p] = out;
+    surfaces_out[p] = out;
+}
+
+// histograms, angle sums, neighbour counts and border sums, norm and per-label extents
+__global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__restrict__ surf32, const int32_t *__restrict__ pat32,
+                                                              const int32_t *__restrict__ edges, const double *__restrict__ lab,
+                                                              const float *__restrict__ angles, const float *__restrict__ points_3d,
+                                                              uint32_t *__restrict__ hist_color, uint32_t *__restrict__ hist_angle,
+                                                              double *__restrict__ angle_sum, uint32_t *__restrict__ cnt,
+                                                              uint32_t *__restrict__ nb_count, unsigned long long *__restrict__ nb_sum,
+                                                              float *__restrict__ norm, uint32_t *__restrict__ extent, int *__restrict__ err,
+                                                              int H, int W, int S)
+{
+    extern __shared__ uint32_t she[];            // [S][8] encoded min/max of (norm, x, y, z) | [S] surface count | [S] patch count
+    uint32_t *s_cnt = she + 8 * S, *p_cnt = s_cnt + S;
+    const int N = H * W;
+    for (int i = threadIdx.x; i < 8 * S; i += SB) she[i] = (i & 1) ? 0u : ~0u;
+    for (int i = threadIdx.x; i < 2 * S; i += SB) s_cnt[i] = 0u;
+    __syncthreads();
+    for (int k = 0; k < SPB / SB; ++k) {
+        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+        if (p >= N) continue;
+        const int y = p / W, x = p - y * W;
+        const int s = surf32[p];
+        // depth extent (every label, 0 included), :332-346
+        const float px = points_3d[3 * (size_t)p], py = points_3d[3 * (size_t)p + 1], pz = points_3d[3 * (size_t)p + 2];
+        const float n = sqrtf((px * px + py * py) + pz * pz);
+        norm[p] = n;
+        if (n != 0.0f) {
+            const float v[4] = {n, px, py, pz};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned e = enc_f32(v[c]);
+                if (e < she[s * 8 + 2 * c]) atomicMin(&she[s * 8 + 2 * c], e);
+                if (e > she[s * 8 + 2 * c + 1]) atomicMax(&she[s * 8 + 2 * c + 1], e);
+            }
+        }
+        if (s > 0) {
+            // colour histogram, :265-267
+            const long a = (long)rint(lab[3 * (size_t)p + 1] + 127.0), b = (long)rint(lab[3 * (size_t)p + 2] + 127.0);
+            if (a < 0 || a > 255 || b < 0 || b > 255) *err = 2;
+            else atomicAdd(hist_color + ((size_t)a * 256 + b) * S + s, 1u);
+            atomicAdd(&s_cnt[s], 1u);
+            // neighbours, :39-55 (pairs with label 0 and pairs of equal labels are zeroed afterwards: skipped)
+            if (edges[p] != 0) {
+                if (y < H - 1) {
+                    const int o = edges[p + W] != 0 ? surf32[p + W] : 0;
+                    if (o != 0 && o != s) {
+                        atomicAdd(nb_count + (size_t)s * S + o, 1u);
+                        atomicAdd(nb_sum + 2 * ((size_t)s * S + o), (unsigned long long)(2 * x + 1));
+                        atomicAdd(nb_sum + 2 * ((size_t)s * S + o) + 1, (unsigned long long)(2 * y));
+                    }
+                }
+                if (x < W - 1) {
+                    const int o = edges[p + 1] != 0 ? surf32[p + 1] : 0;
+                    if (o != 0 && o != s) {
+                        atomicAdd(nb_count + (size_t)s * S + o, 1u);
+                        atomicAdd(nb_sum + 2 * ((size_t)s * S + o), (unsigned long long)(2 * x));
+                        atomicAdd(nb_sum + 2 * ((size_t)s * S + o) + 1, (unsigned long long)(2 * y + 1));
+                    }
+                }
+            }
+            // angle histogram and sums over patch pixels, :269-276
+            const int pl = pat32[p];
+            if (pl > 0) {
+                const float a0 = angles[2 * (size_t)p], a1 = angles[2 * (size_t)p + 1];
+                const int i0 = (int)(((double)a0 / (2 * M_PI) + 0.5) * 39), i1 = (int)(((double)a1 / (2 * M_PI) + 0.5) * 39);
+                if (i0 < 0 || i0 > 39 || i1 < 0 || i1 > 39) *err = 3;
+                else atomicAdd(hist_angle + ((size_t)i0 * 40 + i1) * S + pl, 1u);
+                atomicAdd(angle_sum + 2 * pl, (double)a0);
+                atomicAdd(angle_sum + 2 * pl + 1, (double)a1);
+                atomicAdd(&p_cnt[pl], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * S; i += SB) {
+        const uint32_t v = she[i];
+        if (i & 1) { if (v != 0u) atomicMax(extent + i, v); }
+        else if (v != ~0u) atomicMin(extent + i, v);
+    }
+    for (int i = threadIdx.x; i < 2 * S; i += SB)
+        if (s_cnt[i]) atomicAdd(cnt + i, s_cnt[i]);
+}
+
+// texture vectors of every 4th pixel of a patch, :278-283: one block per texture row, a thread per component
+__global__ __launch_bounds__(SB) void stats_texture_kernel(const int32_t *__restrict__ surf32, const int32_t *__restrict__ pat32,
+                                                           const float *__restrict__ texture, double *__restrict__ tex_sum,
+                                                           uint32_t *__restrict__ tex_cnt, int W, int TW, int T)
+{
+    const int ty = blockIdx.x;
+    // consecutive texture pixels of one label are summed in registers before touching memory
+    for (int c = threadIdx.x; c < T; c += SB) {
+        double run = 0.0;
+        int cur = 0, curn = 0;
+        for (int tx = 0; tx < TW; ++tx) {
+            const size_t p = (size_t)(4 * ty) * W + 4 * tx;
+            const int s = surf32[p] > 0 ? pat32[p] : 0;
+            if (s != cur) {
+                if (cur > 0) {
+                    atomicAdd(tex_sum + (size_t)cur * T + c, run);
+                    if (c == 0) atomicAdd(tex_cnt + cur, (uint32_t)curn);
+                }
+                cur = s; run = 0.0; curn = 0;
+            }
+            if (s > 0) {
+                run += (double)texture[((size_t)ty * TW + tx) * T + c];
+                ++curn;
+            }
+        }
+        if (cur > 0) {
+            atomicAdd(tex_sum + (size_t)cur * T + c, run);
+            if (c == 0) atomicAdd(tex_cnt + cur, (uint32_t)curn);
+        }
+    }
+}
+
+// normalisations of :284-295 and conversion to the float64 outputs
+__global__ __launch_bounds__(SB) void stats_finalize_kernel(const uint32_t *__restrict__ hist_color, const uint32_t *__restrict__ hist_angle,
+                                                            const double *__restrict__ angle_sum, const uint32_t *__restrict__ cnt,
+                                                            const double *__restrict__ tex_sum, const uint32_t *__restrict__ tex_cnt,
+                                                            const uint32_t *__restrict__ extent, double *__restrict__ out_color,
+                                                            double *__restrict__ out_angle, double *__restrict__ out_texture,
+                                                            double *__restrict__ out_avg_angles, float *__restrict__ out_extent, int S, int T)
+{
+    const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
+    const size_t n_color = (size_t)256 * 256 * S, n_angle = (size_t)40 * 40 * S, n_tex = (size_t)S * T;
+    if (i < n_color) {
+        const int s = (int)(i % S);
+        double norm = (double)cnt[s] / 10;
+        if (norm == 0) norm = 1;
+        out_color[i] = (double)hist_color[i] / norm;
+    }
+    if (i < n_angle) {
+        const int s = (int)(i % S);
+        double pc = (double)cnt[S + s];
+        if (pc == 0) pc = 1;
+        out_angle[i] = (double)hist_angle[i] / (pc / 10);
+    }
+    if (i < n_tex) {
+        const int s = (int)(i / T);
+        double c = (double)tex_cnt[s];
+        if (c == 0) c = 1;
+        out_texture[i] = tex_sum[i] / c * 10;
+    }
+    if (i < (size_t)2 * S) {
+        double pc = (double)cnt[S + i / 2];
+        if (pc == 0) pc = 1;
+        out_avg_angles[i] = angle_sum[i] / pc;
+    }
+    if (i < (size_t)8 * S) {
+        const uint32_t e = extent[i];
+        out_extent[i] = (i & 1) ? (e == 0u ? -INFINITY : dec_f32(e)) : (e == ~0u ? INFINITY : dec_f32(e));
+    }
+}
+
+__global__ __launch_bounds__(SB) void stats_fill_kernel(uint32_t *__restrict__ a, size_t n, uint32_t even, uint32_t odd)
+{
+    const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
+    if (i < n) a[i] = (i & 1) ? odd : even;
+}
+
+}  // namespace
+
+size_t stats_sort_temp_bytes(int N)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, N, 0, 10);
+    return bytes;
+}
+
+size_t stats_work_bytes(int S, int T)
+{
+    // acc[4S] u64 | best[2S] u64 | nb_sum[2SS] u64 | angle_sum[2S] f64 | tex_sum[S*T] f64 | hist_color u32 | hist_angle u32 |
+    // nb_count[SS] u32 | cnt[2S] u32 | tex_cnt[S] u32 | extent[8S] u32 | cpix[S] i32 | err i32
+    return 8 * ((size_t)4 * S + 2 * S + 2 * (size_t)S * S + 2 * S + (size_t)S * T) +
+           4 * ((size_t)256 * 256 * S + 1600 * (size_t)S + (size_t)S * S + 2 * S + S + 8 * S + S + 2);
+}
+
+hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const StatsOut &out, int H, int W, int S, int T, hipStream_t st)
+{
+    const int N = H * W;
+    const int nblk = (N + SPB - 1) / SPB;
+    // carve the label-indexed scratch
+    char *base = static_cast<char *>(w.scratch);
+    auto take = [&](size_t bytes) { char *p = base; base += (bytes + 7) / 8 * 8; return p; };
+    auto *acc = reinterpret_cast<unsigned long long *>(take(8 * (size_t)4 * S));
+    auto *best = reinterpret_cast<unsigned long long *>(take(8 * (size_t)2 * S));
+    auto *nb_sum = reinterpret_cast<unsigned long long *>(take(8 * 2 * (size_t)S * S));
+    auto *angle_sum = reinterpret_cast<double *>(take(8 * (size_t)2 * S));
+    auto *tex_sum = reinterpret_cast<double *>(take(8 * (size_t)S * T));
+    auto *hist_color = reinterpret_cast<uint32_t *>(take(4 * (size_t)256 * 256 * S));
+    auto *hist_angle = reinterpret_cast<uint32_t *>(take(4 * (size_t)1600 * S));
+    auto *nb_count = reinterpret_cast<uint32_t *>(take(4 * (size_t)S * S));
+    auto *cnt = reinterpret_cast<uint32_t *>(take(4 * (size_t)2 * S));
+    auto *tex_cnt = reinterpret_cast<uint32_t *>(take(4 * (size_t)S));
+    auto *extent = reinterpret_cast<uint32_t *>(take(4 * (size_t)8 * S));
+    auto *cpix = reinterpret_cast<int32_t *>(take(4 * (size_t)S));
+    auto *err = reinterpret_cast<int *>(take(8));
+    const size_t zero_bytes = (size_t)(reinterpret_cast<char *>(extent) - static_cast<char *>(w.scratch));
+    hipError_t e = hipMemsetAsync(w.scratch, 0, zero_bytes, st);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(best, 0xff, 8 * (size_t)2 * S, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(err, 0, 8, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(stats_fill_kernel, dim3((8 * S + SB - 1) / SB), dim3(SB), 0, st, extent, (size_t)8 * S, ~0u, 0u);
+
+    hipLaunchKernelGGL(stats_prepare_kernel, dim3(nblk), dim3(SB), 4 * S * sizeof(uint32_t), st, in.surfaces, in.patches, w.surf32,
+                       w.pat32, w.sort_key, w.sort_val, acc, err, H, W, S);
+    hipLaunchKernelGGL(stats_offsets_kernel, dim3(1), dim3(1024), 0, st, acc, out.patch_point_offsets, out.avg_pos, out.counts, S);
+    int bits = 1;
+    while ((1 << bits) < S) ++bits;
+    size_t temp = w.sort_temp_bytes;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(w.sort_temp, temp, w.sort_key, w.sort_key_out, w.sort_val, w.sort_val_out, N, 0, bits,
+                                                st)) != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(stats_points_kernel, dim3((N + SB - 1) / SB), dim3(SB), 0, st, w.sort_val_out, reinterpret_cast<float2 *>(out.patch_points), N, W);
+    hipLaunchKernelGGL(stats_centroid_kernel<1>, dim3(nblk), dim3(SB), S * sizeof(unsigned long long), st, w.pat32, out.avg_pos, best, N, W, S);
+    hipLaunchKernelGGL(stats_centroid_kernel<2>, dim3(nblk), dim3(SB), S * sizeof(unsigned long long), st, w.pat32, out.avg_pos, best, N, W, S);
+    hipLaunchKernelGGL(stats_centroid_finish_kernel, dim3((S + SB - 1) / SB), dim3(SB), 0, st, best, in.points_3d, out.centroids,
+                       out.centroid_idx, cpix, W, S);
+    launch_label_components(w.surf32, w.parent, w.count, 1, H, W, st);
+    hipLaunchKernelGGL(stats_keep_kernel, dim3((N + SB - 1) / SB), dim3(SB), 0, st, w.surf32, w.parent, cpix, out.surfaces, N);
+    hipLaunchKernelGGL(stats_accumulate_kernel, dim3(nblk), dim3(SB), 10 * S * sizeof(uint32_t), st, w.surf32, w.pat32, in.depth_edges,
+                       in.lab, in.angles, in.points_3d, hist_color, hist_angle, angle_sum, cnt, nb_count, nb_sum, out.norm, extent, err,
+                       H, W, S);
+    if (in.texture)
+        hipLaunchKernelGGL(stats_texture_kernel, dim3(H / 4), dim3(SB), 0, st, w.surf32, w.pat32, in.texture, tex_sum, tex_cnt, W, W / 4, T);
+    const size_t n_fin = std::max<size_t>((size_t)256 * 256 * S, (size_t)S * T);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((n_fin + SB - 1) / SB)), dim3(SB), 0, st, hist_color, hist_angle, angle_sum,
+                       cnt, tex_sum, tex_cnt, extent, out.hist_color, out.hist_angle, out.hist_texture, out.avg_angles,
+                       out.depth_extend, S, T);
+    if ((e = hipMemcpyAsync(out.nb_count, nb_count, 4 * (size_t)S * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(out.nb_sum, nb_sum, 16 * (size_t)S * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(out.err, err, 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace fs

@@ -1,0 +1,89 @@
+"""Mirror of the per-surface statistics entry point of the reference's process_surfaces module
+(process_surfaces.py:672-689).  The pixel loops (numba in the reference) run in fs_surface_stats on
+the GPU; what is left here is arithmetic on S x S or S-sized arrays, in numpy like the reference."""
+import numpy as np
+
+from . import find_surfaces as _fs
+from . import utils
+
+
+def determine_even_planes(data):
+    """1 for surfaces whose normalised angle histogram is peaked (process_surfaces.py:464-478)."""
+    hist = np.swapaxes(data["hist_angle"], 2, 0)                   # [S, 40, 40]
+    total = hist.sum(axis=(-1, -2), keepdims=True)
+    total[total == 0] = 1
+    p = hist / total
+    entropy = -np.sum(p * np.log(np.where(p == 0, 1.0, p)), axis=(-1, -2))
+    peak = hist.max(axis=(-1, -2))
+    planes = np.zeros(data["num_surfaces"])
+    planes[peak >= 1.5] = 1.0
+    planes[entropy > 2] = 0.0
+    planes[peak >= 3] = 1.0
+    return planes
+
+
+def calc_depth_extend_distance(i, j, depth_extends):
+    """Largest gap between the (norm, x, y, z) intervals of two surfaces, 0 where they overlap
+    (process_surfaces.py:317-329)."""
+    d1, d2 = depth_extends[i], depth_extends[j]
+    overlap = ((d2[:, 0] <= d1[:, 0]) & (d1[:, 0] <= d2[:, 1])) | ((d2[:, 0] <= d1[:, 1]) & (d1[:, 1] <= d2[:, 1])) | \
+              ((d1[:, 0] <= d2[:, 0]) & (d2[:, 1] <= d1[:, 1]))
+    gap = np.where(d1[:, 0] > d2[:, 1], d1[:, 0] - d2[:, 1], d2[:, 0] - d1[:, 1])
+    gap[overlap] = 0
+    return np.max(gap)
+
+
+def create_depth_extend_distance_matrix(data):
+    """Symmetric matrix of calc_depth_extend_distance (process_surfaces.py:552-560)."""
+    S = data["num_surfaces"]
+    out = np.zeros((S, S))
+    for i in range(S):
+        for j in range(i + 1, S):
+            out[i, j] = out[j, i] = calc_depth_extend_distance(i, j, data["depth_extend"])
+    return out
+
+
+def calc_depth_extend_to_depth_extend_distance_ratio(data):
+    """Distance over the mean interval length of the pair (process_surfaces.py:664-670)."""
+    size = np.sum(np.abs(data["depth_extend"][:, :, 0] - data["depth_extend"][:, :, 1]), axis=-1, keepdims=True) / 4
+    pair = (size + size.T) / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = data["depth_extend_distances"] / pair
+    ratio[np.isnan(ratio)] = 0
+    return ratio
+
+
+def neighbor_lists(neighbor_counts):
+    """Per surface the labels j >= 1 with more than 3 shared border pixels (process_surfaces.py:70-77)."""
+    S = len(neighbor_counts)
+    return [[j for j in range(1, S) if neighbor_counts[i][j] > 3] for i in range(S)]
+
+
+def extract_information_from_surface_data_and_preprocess_surfaces(data, texture_model):
+    """Adds the per-surface statistics to `data` (process_surfaces.py:672-689): patch_points, surfaces
+    (relabelled, disconnected parts removed), avg_pos, counts, centroids, texture, lab, hist_color,
+    hist_angle, hist_texture, avg_normals, planes, neighbors, border_centers, norm, depth_extend,
+    depth_extend_distances, depth_extend_distance_ratio.  texture_model(rgb) -> [H/4, W/4, T] float
+    array (the reference's ResNet feature extractor; not part of this build) or None."""
+    h, w = np.shape(data["patches"])
+    S = int(data["num_surfaces"])
+    data["texture"] = None if texture_model is None else texture_model(data["rgb"])
+    if "lab" not in data:
+        data["lab"] = utils.rgb_to_Lab(data["rgb"])
+    ctx = _fs._context(h, w, _fs.standard_kernel_size)
+    st = ctx.surface_stats(data["surfaces"], data["patches"], data["depth_edges"], data["points_3d"], data["angles"], data["lab"],
+                           data["texture"], S)
+    off = st["patch_point_offsets"]
+    data["patch_points"] = [st["patch_points"][off[i]:off[i + 1]] for i in range(S)]
+    data["surfaces"] = st["surfaces"]
+    data["avg_pos"], data["counts"] = st["avg_pos"], st["counts"]
+    data["centroids"] = st["centroids"]
+    data["hist_color"], data["hist_angle"], data["hist_texture"] = st["hist_color"], st["hist_angle"], st["hist_texture"]
+    data["avg_normals"] = utils.angles_to_normals(st["avg_angles"])
+    data["planes"] = determine_even_planes(data)
+    data["neighbors"], data["border_centers"] = neighbor_lists(st["neighbor_counts"]), st["border_centers"]
+    data["norm"] = st["norm"]
+    data["depth_extend"] = st["depth_extend"]
+    data["depth_extend_distances"] = create_depth_extend_distance_matrix(data) / 1000
+    data["depth_extend_distance_ratio"] = calc_depth_extend_to_depth_extend_distance_ratio(data)
+    return data

@@ -114,6 +114,32 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
 int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *depth, const uint8_t *rgb,
                  const float *angles, int64_t *out);
 
+/* ---- per-surface statistics ---------------------------------------------------
+ * The pixel-level part of process_surfaces.extract_information_from_surface_data_and_preprocess_surfaces
+ * (process_surfaces.py:672-687) for one frame, host pointers, in the reference's order:
+ *   extract_individual_points_from_surfaces (:96-108)  -> patch_point_offsets int32 [S+1],
+ *       patch_points float32 [H*W][2] = (x, y) grouped by patch label, raster order inside a label
+ *   relabel_surfaces (:236-242), determine_pixel_counts_and_average_position_for_patches (:111-129)
+ *       -> avg_pos float64 [S][2] = (x, y), counts float64 [S]
+ *   determine_surface_patch_centroids (:81-93) -> centroids float32 [S][3], centroid_indices int32 [S][2] = (y, x);
+ *       a label without patch pixels gets -1 entries at its own position
+ *   remove_disconnected_components (:8-28) -> surfaces_out int64 [H][W]
+ *   determine_histograms_and_average_normals (:245-297) -> hist_color float64 [256][256][S], hist_angle float64
+ *       [40][40][S], hist_texture float64 [S][texture_dim], avg_angles float64 [S][2] (the input of
+ *       utils.angles_to_normals); lab float64 [H][W][3] and texture float32 [H/4][W/4][texture_dim] (may be
+ *       NULL) are inputs, as in the reference
+ *   determine_neighboring_surfaces_and_border_centers (:31-68) -> neighbors float64 [S][S] (pair counts after the
+ *       "< 4 -> 1" rule; the neighbour list of :70-77 is neighbors[i][j] > 3 for j >= 1), border_centers float64 [S][S][2]
+ *   norm (:686) float32 [H][W], calculate_depth_extend (:332-346) -> depth_extend float32 [S][4][2]
+ * S = num_surfaces; every label of surfaces and patches must lie in [0, S).  Output pointers may be NULL
+ * (neighbors and border_centers only together). */
+int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, const int64_t *patches,
+                     const int32_t *depth_edges, const float *points_3d, const float *angles, const double *lab,
+                     const float *texture, int texture_dim, int64_t *surfaces_out, int32_t *patch_point_offsets,
+                     float *patch_points, double *avg_pos, double *counts, float *centroids, int32_t *centroid_indices,
+                     double *hist_color, double *hist_angle, double *hist_texture, double *avg_angles, double *neighbors,
+                     double *border_centers, float *norm, float *depth_extend);
+
 /* ---- instrumentation -------------------------------------------------------
  * group_mask bit g set: HIP events are recorded on the context's stream around
  * every launch of kernel group g; fs_get_timing() synchronises and returns the

@@ -201,3 +201,47 @@ def gauss_params():
     p.append(0.01)
     p[3] = 0
     return np.asarray(p, np.float32)
+
+
+# ---------------------------------------------------------------------------
+# per-surface statistics (fs_oracle_stats.c; process_surfaces.py:672-689)
+# ---------------------------------------------------------------------------
+def extract_points(patches, S):
+    p = _c(patches, np.int64)
+    H, W = p.shape
+    off, pts = np.empty(S + 1, np.int32), np.empty((H * W, 2), np.float32)
+    lib().fso_extract_points(_p(p), H, W, S, _p(off), _p(pts))
+    return off, pts
+
+
+def surface_stats(surfaces, patches, depth_edges, points_3d, angles, lab, texture, num_surfaces):
+    """The pixel-level part of extract_information_from_surface_data_and_preprocess_surfaces
+    (process_surfaces.py:672-687) in its order.  Returns a dict of arrays."""
+    L = lib()
+    S = int(num_surfaces)
+    surf = _c(surfaces, np.int64).copy()
+    pat = _c(patches, np.int64)
+    H, W = pat.shape
+    edges, pts3, ang = _c(depth_edges, np.int32), _c(points_3d, np.float32), _c(angles, np.float32)
+    lab = _c(lab, np.float64)
+    tex = None if texture is None else _c(texture, np.float32)
+    T = 256 if tex is None else tex.shape[-1]
+    out = {}
+    off, pp = extract_points(pat, S)
+    out["patch_point_offsets"], out["patch_points"] = off, pp
+    L.fso_relabel(_p(surf), _p(pat), H * W)
+    avg, cnt = np.empty((S, 2)), np.empty((S, 1))
+    L.fso_counts_avg_pos(_p(surf), H, W, S, _p(avg), _p(cnt))
+    cen, cidx = np.empty((S, 3), np.float32), np.empty((S, 2), np.int32)
+    L.fso_centroids(_p(pp), _p(off), _p(avg), _p(pts3), S, W, _p(cen), _p(cidx))
+    L.fso_remove_disconnected(_p(surf), H, W, _p(cidx), S)
+    hc, ha = np.empty((256, 256, S)), np.empty((40, 40, S))
+    ht, aa = np.empty((S, T)), np.empty((S, 2))
+    L.fso_histograms(_p(lab), _p(ang), _p(tex), T, _p(surf), _p(pat), H, W, S, _p(hc), _p(ha), _p(ht), _p(aa))
+    nb, bc = np.empty((S, S)), np.empty((S, S, 2))
+    L.fso_neighbors(_p(surf), _p(edges), H, W, S, _p(nb), _p(bc))
+    norm, de = np.empty((H, W), np.float32), np.empty((S, 4, 2), np.float32)
+    L.fso_depth_extend(_p(surf), _p(pts3), H, W, S, _p(norm), _p(de))
+    out.update(surfaces=surf, avg_pos=avg, counts=cnt, centroids=cen, centroid_indices=cidx, hist_color=hc, hist_angle=ha,
+               hist_texture=ht, avg_angles=aa, neighbor_counts=nb, border_centers=bc, norm=norm, depth_extend=de)
+    return out

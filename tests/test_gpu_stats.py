@@ -1,0 +1,107 @@
+"""GPU parity of the per-surface statistics stage (fs_surface_stats) against the C oracle
+(oracle/fs_oracle_stats.c).  Integer results -- labels, point lists, counts, centroid indices,
+histogram counts, neighbour counts -- are compared bit for bit (the float64 arrays derived from
+integers by one division are equal too); float64 sums of float32 values (average angles, texture)
+within 1e-12 relative, since the order of additions differs."""
+import numpy as np
+import pytest
+
+from conftest import osd_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(oracle, index):
+    from imagesegmentation_amd.utils import rgb_to_Lab
+    d, c = osd_frame(index)
+    ref = oracle.find_surfaces(d, c, oracle.gauss_params())
+    rng = np.random.default_rng(index)
+    tex = rng.random((120, 160, 256), dtype=np.float32)
+    return ref, rgb_to_Lab(c), tex
+
+
+@pytest.mark.parametrize("index", [57, 110])
+def test_surface_stats_osd(oracle, index):
+    from imagesegmentation_amd._lib import Context
+    ref, lab, tex = _frame(oracle, index)
+    S = ref["num_surfaces"]
+    args = (ref["surfaces"], ref["patches"], ref["depth_edges"], ref["points_3d"], ref["angles"], lab, tex, S)
+    want = oracle.surface_stats(*args)
+    with Context(480, 640) as ctx:
+        got = ctx.surface_stats(*args)
+    exact = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+             "hist_color", "hist_angle", "neighbor_counts", "border_centers", "norm", "depth_extend")
+    for k in exact:
+        assert np.array_equal(got[k], want[k]), k
+    for k in ("avg_angles", "hist_texture"):
+        assert np.allclose(got[k], want[k], rtol=1e-12, atol=1e-13), k
+    assert got["surfaces"].dtype == np.int64 and got["depth_extend"].dtype == np.float32
+    assert (want["neighbor_counts"] > 3).any()          # the frame has real neighbours
+    assert (got["surfaces"] != ref["surfaces"]).any() or index == 110
+
+
+def test_surface_stats_disconnected_parts_and_edge_cases(oracle):
+    """Hand-made labelling: a label split in two parts (the part away from the centroid goes), a label
+    without patch pixels (dropped entirely), no texture input."""
+    from imagesegmentation_amd._lib import Context
+    H, W, S = 32, 48, 5
+    surfaces = np.zeros((H, W), np.int64)
+    patches = np.zeros((H, W), np.int64)
+    surfaces[2:12, 2:20] = 1
+    patches[4:10, 4:16] = 1
+    surfaces[20:24, 30:34] = 1            # disconnected part of label 1
+    surfaces[14:30, 4:20] = 2
+    patches[16:28, 6:18] = 2
+    surfaces[2:10, 30:44] = 3             # label 3 has no patch pixels at all
+    edges = np.ones((H, W), np.int32)
+    edges[12:14, :] = 0
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(H, W, 3)).astype(np.float32) * 100
+    pts[0, :5] = 0                        # zero-norm pixels are skipped by the extent
+    ang = (rng.random((H, W, 2), dtype=np.float32) - 0.5) * 6
+    lab = np.stack([rng.random((H, W)) * 100, rng.random((H, W)) * 200 - 100, rng.random((H, W)) * 200 - 100], -1)
+    args = (surfaces, patches, edges, pts, ang, lab, None, S)
+    want = oracle.surface_stats(*args)
+    with Context(H, W) as ctx:
+        got = ctx.surface_stats(*args)
+    assert (want["surfaces"][20:24, 30:34] == 0).all() and (want["surfaces"] != 3).all()
+    assert tuple(want["centroid_indices"][3]) == (-1, -1) and tuple(want["centroid_indices"][4]) == (-1, -1)
+    for k in ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+              "hist_color", "hist_angle", "neighbor_counts", "border_centers", "norm", "depth_extend", "hist_texture"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.allclose(got["avg_angles"], want["avg_angles"], rtol=1e-12, atol=1e-13)
+    assert np.isinf(got["depth_extend"][4]).all()
+    # labels outside [0, S) are refused
+    bad = surfaces.copy()
+    bad[0, 0] = S
+    with Context(H, W) as ctx:
+        with pytest.raises(RuntimeError):
+            ctx.surface_stats(bad, patches, edges, pts, ang, lab, None, S)
+
+
+def test_process_surfaces_mirror_keys(oracle):
+    """find_surface_model -> extract_information_from_surface_data_and_preprocess_surfaces, the
+    sequence of the reference's prediction models, with the keys downstream code reads."""
+    from imagesegmentation_amd import find_surfaces as fs
+    from imagesegmentation_amd import process_surfaces as ps
+    data = fs.find_surface_model("Gauss")(fs.load_image(20))
+    before = {k: np.copy(data[k]) for k in ("surfaces", "patches", "depth_edges", "points_3d", "angles")}
+    rng = np.random.default_rng(0)
+    tex = rng.random((120, 160, 256), dtype=np.float32)
+    ps.extract_information_from_surface_data_and_preprocess_surfaces(data, lambda rgb: tex)
+    S = data["num_surfaces"]
+    for k in ("patch_points", "surfaces", "avg_pos", "counts", "centroids", "texture", "lab", "hist_color", "hist_angle",
+              "hist_texture", "avg_normals", "planes", "neighbors", "border_centers", "norm", "depth_extend",
+              "depth_extend_distances", "depth_extend_distance_ratio"):
+        assert k in data, k
+    assert len(data["patch_points"]) == S and data["patch_points"][1].dtype == np.float32
+    assert data["counts"].shape == (S, 1) and data["avg_pos"].shape == (S, 2) and data["centroids"].shape == (S, 3)
+    assert data["hist_color"].shape == (256, 256, S) and data["hist_angle"].shape == (40, 40, S)
+    assert data["avg_normals"].shape == (S, 3) and data["planes"].shape == (S,)
+    assert data["depth_extend_distances"].shape == (S, S) and len(data["neighbors"]) == S
+    want = oracle.surface_stats(before["surfaces"], before["patches"], before["depth_edges"], before["points_3d"],
+                                before["angles"], data["lab"], tex, S)
+    assert np.array_equal(data["surfaces"], want["surfaces"])
+    assert np.array_equal(data["depth_extend"], want["depth_extend"])
+    assert data["neighbors"] == ps.neighbor_lists(want["neighbor_counts"])
+    assert np.allclose(np.linalg.norm(data["avg_normals"][1:], axis=-1), 1)
