@@ -144,16 +144,20 @@ int build_pos_terms(fs_ctx *ctx)
         }
     FS_HIP(ctx->pos_terms.ensure(pt.size() * sizeof(float)));
     FS_HIP(hipMemcpy(ctx->pos_terms.p, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
-    // per-offset weights of the fused update: w_k * exp(-position term of kernel k) over the full window
+    // per-offset constants of the fused update over the full window: (w1', w2', w3', bias) with
+    // w_k' = w_k * exp(-position term of kernel k); zeros at the centre (excluded from the message,
+    // find_surfaces.py:300-302) and in one extra row used for neighbour rows out of a pixel's reach
     const int kw = 2 * r + 1;
-    std::vector<float> wt((size_t)4 * kw * kw, 0.0f);
+    std::vector<float> wt((size_t)4 * (kw + 1) * kw, 0.0f);
     for (int dy = -r; dy <= r; ++dy)
         for (int dx = -r; dx <= r; ++dx) {
+            if (dy == 0 && dx == 0) continue;
             const double q = ((double)dy / 40.0) * ((double)dy / 40.0) + ((double)dx / 40.0) * ((double)dx / 40.0);
             float *w = &wt[4 * ((size_t)(dy + r) * kw + dx + r)];
             w[0] = (float)(ctx->params.w1 * std::exp(-(double)ctx->params.t11 * q));
             w[1] = (float)(ctx->params.w2 * std::exp(-(double)ctx->params.t21 * q));
             w[2] = (float)(ctx->params.w3 * std::exp(-(double)ctx->params.t31 * q));
+            w[3] = ctx->params.bias;
         }
     FS_HIP(ctx->wtab.ensure(wt.size() * sizeof(float)));
     FS_HIP(hipMemcpy(ctx->wtab.p, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));

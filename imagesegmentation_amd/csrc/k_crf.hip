@@ -529,6 +529,82 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 struct FusedConsts { float K1, K2, K3, C2, C3, bias; };
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
+// Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
+// from the staged chunk: acc[i][k] += sum over the window of sim(pixel i, neighbour) * Q_neighbour[k].
+// Both rows are carried as packed pairs, one v_pk_* instruction per operation.  wtab holds, per window
+// offset, (w1', w2', w3', bias) with zeros at the centre and in one extra row that serves the row of
+// the pair that a neighbour row does not reach, so no masking is left in the loop.
+// The relative depth difference divides by (d_p + d_q): a lane whose own depth is 0 may produce
+// NaN here; its result is overridden afterwards (Q[depth == 0]) and never read.
+template <int R, int NQ>
+__device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float4 *lds4, int plane4, int LW, int trow, int col, int r,
+                                                 const FusedConsts &K, const float4 *__restrict__ wtab)
+{
+    const int kw = 2 * r + 1;
+    const float4 *featA = lds4 + 2 * plane4;
+    const float2 *featB = reinterpret_cast<const float2 *>(featA + plane4);
+    f2 cd, cr, cg, cb, ca0, ca1;
+    {
+        const int c0 = (trow + r) * LW + col + r, c1 = c0 + LW;
+        const float4 a0 = featA[c0], a1 = featA[c1];
+        const float2 b0 = featB[c0], b1 = featB[c1];
+        cd = f2{a0.x, a1.x}; cr = f2{a0.y, a1.y}; cg = f2{a0.z, a1.z}; cb = f2{a0.w, a1.w};
+        ca0 = f2{b0.x, b1.x}; ca1 = f2{b0.y, b1.y};
+    }
+    // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i
+    for (int jr = 0; jr < 2 + 2 * r; ++jr) {
+        const int rowbase = (trow + jr) * LW + col;       // window column dx = -r (LDS offsets are unsigned)
+        // one opaque LDS index per plane, so that every read of the row is base register + immediate
+        int iQ0 = rowbase, iQ1 = rowbase + plane4, iA = rowbase + 2 * plane4, iB = rowbase + 6 * plane4;
+        asm volatile("" : "+v"(iQ0), "+v"(iQ1), "+v"(iA), "+v"(iB));
+        const float4 *rowQ0 = lds4 + iQ0, *rowQ1 = lds4 + iQ1, *rowA = lds4 + iA;
+        const float2 *rowB = reinterpret_cast<const float2 *>(lds4) + iB;
+        const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : kw) * kw + r;          // weights of row 0's dy (zero row when out of reach)
+        const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : kw) * kw + r;          // ... and of row 1's
+#pragma unroll
+        for (int dx = -r; dx <= r; ++dx) {
+            const float4 fa = rowA[dx + r];
+            const float2 fb = rowB[dx + r];
+            const float4 q0 = rowQ0[dx + r];
+            float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NQ > 1) q1 = rowQ1[dx + r];
+            const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
+            const f2 dj = f2{fa.x, fa.x};
+            const f2 den = cd + dj;
+            const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            const f2 t = (dj - cd) * inv;
+            const f2 u = t * t;
+            const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
+            const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
+            const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
+            const f2 ea = __builtin_elementwise_fma(g1, g1, g0 * g0);
+            const f2 x1 = f2{K.K1, K.K1} * u;
+            const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
+            const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
+            const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
+            const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
+            const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
+            const f2 sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
+                          __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
+                          __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float sI = i == 0 ? sv.x : sv.y;
+                acc[i][0] = fmaf(sI, q0.x, acc[i][0]);
+                acc[i][1] = fmaf(sI, q0.y, acc[i][1]);
+                acc[i][2] = fmaf(sI, q0.z, acc[i][2]);
+                acc[i][3] = fmaf(sI, q0.w, acc[i][3]);
+                if (NQ > 1) {
+                    acc[i][4] = fmaf(sI, q1.x, acc[i][4]);
+                    acc[i][5] = fmaf(sI, q1.y, acc[i][5]);
+                    acc[i][6] = fmaf(sI, q1.z, acc[i][6]);
+                    acc[i][7] = fmaf(sI, q1.w, acc[i][7]);
+                }
+            }
+        }
+    }
+}
+
 template <int R, int TH, int NCH>
 __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last)
@@ -618,7 +694,6 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
 #pragma unroll
             for (int k = 0; k < CH; ++k) acc[c][i][k] = 0.0f;
 
-    const int kw = 2 * r + 1;
     const int ns = S - 1;
     const float q_pv = (float)(1.0 / (double)ns), q_other = (float)(1.0 / (double)(ns - 1) * 0.1);
     __syncthreads();                                        // s_src, features
@@ -654,74 +729,14 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
                         }
                     }
                     lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
-                    lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
+                    if (CE - ch * CH > 4) lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
                 }
             }
             __syncthreads();
             if (wave_work && FS_SKIPMAIN == 0) {
-                // both rows of the lane as packed pairs: one v_pk_* instruction per operation
-                f2 cd, cr, cg, cb, ca0, ca1;
-                {
-                    const int c0 = (trow + r) * LW + col + r, c1 = c0 + LW;
-                    const float4 a0 = featA[c0], a1 = featA[c1];
-                    const float2 b0 = featB[c0], b1 = featB[c1];
-                    cd = f2{a0.x, a1.x}; cr = f2{a0.y, a1.y}; cg = f2{a0.z, a1.z}; cb = f2{a0.w, a1.w};
-                    ca0 = f2{b0.x, b1.x}; ca1 = f2{b0.y, b1.y};
-                }
-                const f2 tiny = f2{1e-30f, 1e-30f};
-                // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i
-                for (int jr = 0; jr < 2 + 2 * r; ++jr) {
-                    const int rowbase = (trow + jr) * LW + col;       // window column dx = -r (LDS offsets are unsigned)
-                    // one opaque LDS index per plane, so that every read of the row is base register + immediate
-                    int iQ0 = rowbase, iQ1 = rowbase + plane4, iA = rowbase + 2 * plane4, iB = rowbase + 6 * plane4;
-                    asm volatile("" : "+v"(iQ0), "+v"(iQ1), "+v"(iA), "+v"(iB));
-                    const float4 *rowQ0 = lds4 + iQ0, *rowQ1 = lds4 + iQ1, *rowA = lds4 + iA;
-                    const float2 *rowB = reinterpret_cast<const float2 *>(lds4) + iB;
-                    const float m0 = jr <= 2 * r ? 1.0f : 0.0f;      // row 0: dy = jr - r      in [-r, r]
-                    const float m1 = jr >= 1 ? 1.0f : 0.0f;          // row 1: dy = jr - r - 1  in [-r, r]
-                    const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : 0) * kw + r;          // weights of row 0's dy
-                    const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : 0) * kw + r;          // ... and of row 1's
-#pragma unroll
-                    for (int dx = -r; dx <= r; ++dx) {
-                        const float4 fa = rowA[dx + r];
-                        const float2 fb = rowB[dx + r];
-                        const float4 q0 = rowQ0[dx + r], q1 = rowQ1[dx + r];
-                        const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
-                        f2 mk = f2{m0, m1};
-                        if (dx == 0) mk = f2{jr == r ? 0.0f : m0, jr == r + 1 ? 0.0f : m1};      // centre excluded
-                        const f2 dj = f2{fa.x, fa.x};
-                        const f2 den = __builtin_elementwise_max(cd + dj, tiny);                // both depths 0 -> t = 0
-                        const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                        const f2 t = (dj - cd) * inv;
-                        const f2 u = t * t;
-                        const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
-                        const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
-                        const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
-                        const f2 ea = __builtin_elementwise_fma(g1, g1, g0 * g0);
-                        const f2 x1 = f2{K.K1, K.K1} * u;
-                        const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
-                        const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
-                        const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
-                        const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
-                        const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
-                        f2 sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
-                                __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
-                                __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{K.bias, K.bias})));
-                        sv = sv * mk;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const float sI = i == 0 ? sv.x : sv.y;
-                            acc[ch][i][0] = fmaf(sI, q0.x, acc[ch][i][0]);
-                            acc[ch][i][1] = fmaf(sI, q0.y, acc[ch][i][1]);
-                            acc[ch][i][2] = fmaf(sI, q0.z, acc[ch][i][2]);
-                            acc[ch][i][3] = fmaf(sI, q0.w, acc[ch][i][3]);
-                            acc[ch][i][4] = fmaf(sI, q1.x, acc[ch][i][4]);
-                            acc[ch][i][5] = fmaf(sI, q1.y, acc[ch][i][5]);
-                            acc[ch][i][6] = fmaf(sI, q1.z, acc[ch][i][6]);
-                            acc[ch][i][7] = fmaf(sI, q1.w, acc[ch][i][7]);
-                        }
-                    }
-                }
+                // 1..4 channels of the chunk need only the first quad plane (two thirds of all tiles)
+                if (CE - ch * CH <= 4) fused_accumulate<R, 1>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                else fused_accumulate<R, 2>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
             }
         }
     }
