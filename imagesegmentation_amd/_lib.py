@@ -25,6 +25,7 @@ SIGNATURES = {
     "fs_last_error": (_c.c_char_p, [_vp]),
     "fs_set_view_angles": (_i, [_vp, _d, _d]),
     "fs_set_gauss_params": (_i, [_vp, _vp]),
+    "fs_set_lr_params": (_i, [_vp, _vp]),
     "fs_set_kernel_size": (_i, [_vp, _i]),
     "fs_set_stream": (_i, [_vp, _vp]),
     "fs_stream": (_vp, [_vp]),
@@ -33,6 +34,7 @@ SIGNATURES = {
     "fs_patches": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_connected_components": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "fs_crf_step": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fs_crf_step_lr": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -70,6 +72,14 @@ def gauss_parameters():
     return np.asarray(p, np.float32)
 
 
+def lr_parameters():
+    """(coef[4], intercept + 4, weight, auxiliary weight): load_pixel_similarity_parameters
+    (find_surfaces.py:216-218) and LR_CRF_parameters (:22) from the JSON copy of the shipped values."""
+    with open(os.path.join(_HERE, "params", "lr.json")) as f:
+        doc = json.load(f)
+    return np.asarray(list(doc["coef"]) + [doc["intercept"] + 4, 0.01, 15000], np.float32)
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -96,7 +106,10 @@ class Context:
             raise RuntimeError("fs_create failed: " + self._lib.fs_last_error(None).decode())
         self.kernel_size = 7
         self.set_kernel_size(kernel_size)
-        self.set_gauss_params(gauss_parameters() if params is None else params)
+        if params is not None and len(np.reshape(params, -1)) == 7:
+            self.set_lr_params(params)
+        else:
+            self.set_gauss_params(gauss_parameters() if params is None else params)
 
     # -- plumbing -----------------------------------------------------------
     def _check(self, rc):
@@ -124,6 +137,11 @@ class Context:
         p = _arr(np.asarray(params, np.float32).reshape(-1), np.float32, (13,))
         self.params = p
         self._check(self._lib.fs_set_gauss_params(self._h, _ptr(p)))
+
+    def set_lr_params(self, params):
+        p = _arr(np.asarray(params, np.float32).reshape(-1), np.float32, (7,))
+        self.params = p
+        self._check(self._lib.fs_set_lr_params(self._h, _ptr(p)))
 
     def set_kernel_size(self, r):
         self._check(self._lib.fs_set_kernel_size(self._h, int(r)))
@@ -205,6 +223,20 @@ class Context:
         pot = np.empty((B, h, w, S), np.float32) if want_potentials else None
         self._check(self._lib.fs_crf_step(self._h, B, h, w, S, _ptr(unary), _ptr(Q), _ptr(f1), _ptr(f2), _ptr(f3),
                                           _ptr(val), _ptr(out), _ptr(pot)))
+        return (out, pot) if want_potentials else out
+
+    def crf_step_lr(self, unary, Q, f1, f2, f3, f4, val, want_potentials=False):
+        unary = _arr(unary, np.float32)
+        B, h, w, S = unary.shape
+        r = self.kernel_size
+        pad = (B, h + 2 * r, w + 2 * r)
+        Q = _arr(Q, np.float32, pad + (S,))
+        f1, f2, f3, f4 = (_arr(f, np.float32, pad + (c,)) for f, c in ((f1, 1), (f2, 2), (f3, 3), (f4, 2)))
+        val = _arr(np.asarray(val, np.float32).reshape(-1, S)[0], np.float32)
+        out = np.empty((B, h, w, S), np.float32)
+        pot = np.empty((B, h, w, S), np.float32) if want_potentials else None
+        self._check(self._lib.fs_crf_step_lr(self._h, B, h, w, S, _ptr(unary), _ptr(Q), _ptr(f1), _ptr(f2), _ptr(f3), _ptr(f4),
+                                             _ptr(val), _ptr(out), _ptr(pot)))
         return (out, pot) if want_potentials else out
 
     # -- fused path --------------------------------------------------------------

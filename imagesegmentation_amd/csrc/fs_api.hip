@@ -154,6 +154,15 @@ int build_pos_terms(fs_ctx *ctx)
             if (dy == 0 && dx == 0) continue;
             const double q = ((double)dy / 40.0) * ((double)dy / 40.0) + ((double)dx / 40.0) * ((double)dx / 40.0);
             float *w = &wt[4 * ((size_t)(dy + r) * kw + dx + r)];
+            if (ctx->params.mode == 1) {
+                // linear similarity: weights of |relative depth difference| * 6, angle distance * 2, colour distance / 50;
+                // the position distance |offset| / 40 is a constant of the offset and joins the bias
+                w[0] = 6.0f * ctx->params.lr_coef[0];
+                w[1] = 2.0f * ctx->params.lr_coef[1];
+                w[2] = (float)(ctx->params.lr_coef[2] / 50.0);
+                w[3] = (float)((double)ctx->params.bias + (double)ctx->params.lr_coef[3] * (std::sqrt((double)(dy * dy + dx * dx)) / 40.0));
+                continue;
+            }
             w[0] = (float)(ctx->params.w1 * std::exp(-(double)ctx->params.t11 * q));
             w[1] = (float)(ctx->params.w2 * std::exp(-(double)ctx->params.t21 * q));
             w[2] = (float)(ctx->params.w3 * std::exp(-(double)ctx->params.t31 * q));
@@ -270,6 +279,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
     const bool fused = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;
+    if (!fused && ctx->params.mode == 1) return ctx->fail("the logistic-regression similarity is only available in the fused update");
     int tiles_x = 0, tiles_y = 0;
     if (fused) crf_fused_tile_grid(H, W, ctx->r, &tiles_x, &tiles_y);
     const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
@@ -361,7 +371,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             for (const Launch &l : launches[(size_t)gi * iterations + it]) {
                 const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
                 hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, ctx->stream)
-                                     : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, mode, ctx->stream);
+                                     : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }
         }
@@ -446,6 +456,22 @@ int fs_set_gauss_params(fs_ctx *ctx, const float p[13])
     q.t12 = p[7] * p[7]; q.t22 = p[8] * p[8]; q.t32 = p[9] * p[9];
     q.t23 = p[10] * p[10]; q.t33 = p[11] * p[11];
     q.weight = p[12];
+    q.evidence = 0.00005f;
+    q.mode = 0;
+    ctx->have_params = true;
+    return build_pos_terms(ctx);
+}
+
+int fs_set_lr_params(fs_ctx *ctx, const float p[7])
+{
+    if (!ctx || !p) return -1;
+    if (set_device(ctx)) return -1;
+    CrfParams &q = ctx->params;
+    for (int i = 0; i < 4; ++i) q.lr_coef[i] = p[i];
+    q.bias = p[4];
+    q.weight = p[5];
+    q.evidence = p[6];
+    q.mode = 1;
     ctx->have_params = true;
     return build_pos_terms(ctx);
 }
@@ -559,7 +585,7 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
 {
     if (!ctx) return -1;
     if (set_device(ctx)) return -1;
-    if (!ctx->have_params) return ctx->fail("fs_crf_step: call fs_set_gauss_params first");
+    if (!ctx->have_params || ctx->params.mode != 0) return ctx->fail("fs_crf_step: call fs_set_gauss_params first");
     if (B < 1 || h < 1 || w < 1 || S < 2) return ctx->fail("fs_crf_step: bad shape");
     if (S > kMaxTileChannels) return ctx->fail("fs_crf_step: at most " + std::to_string(kMaxTileChannels) + " label channels");
     for (int l = 0; l < S; ++l)
@@ -599,7 +625,7 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
         FS_HIP(hipMemcpyAsync(ctx->f2.p, f2 + (size_t)b * NP * 6, NP * 6 * 4, hipMemcpyHostToDevice, ctx->stream));
         FS_HIP(hipMemcpyAsync(ctx->f3.p, f3 + (size_t)b * NP * 5, NP * 5 * 4, hipMemcpyHostToDevice, ctx->stream));
         launch_crf_sim_explicit(ctx->f1.as<float>(), ctx->f2.as<float>(), ctx->f3.as<float>(), ctx->params, sim0, hp, wp, r, ctx->stream);
-        hipError_t e = launch_crf_iter(ctx->descs.as<CrfFrameDesc>(), 1, crf_channel_class(S), geom, ctx->params.weight, 0, ctx->stream);
+        hipError_t e = launch_crf_iter(ctx->descs.as<CrfFrameDesc>(), 1, crf_channel_class(S), geom, ctx->params.weight, ctx->params.evidence, 0, ctx->stream);
         if (e != hipSuccess) return ctx->fail(e, "fs_crf_step: launch");
         launch_planes_to_rows(ctx->qb.as<float>(), rows, NO, S, ctx->stream);
         FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, rows, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -607,6 +633,43 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
             launch_planes_to_rows(ctx->pot.as<float>(), rows, NO, S, ctx->stream);
             FS_HIP(hipMemcpyAsync(potentials + (size_t)b * NO * S, rows, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, const float *Q, const float *f1, const float *f2,
+                   const float *f3, const float *f4, const float *val, float *out, float *potentials)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (!ctx->have_params || ctx->params.mode != 1) return ctx->fail("fs_crf_step_lr: call fs_set_lr_params first");
+    if (B < 1 || h < 1 || w < 1 || S < 2 || S > kMaxLabels) return ctx->fail("fs_crf_step_lr: bad shape");
+    for (int l = 0; l < S; ++l)
+        if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step_lr: val must be the one-hot of the last label");
+    const int r = ctx->r;
+    const size_t NP = (size_t)(h + 2 * r) * (w + 2 * r), NO = (size_t)h * w;
+    FS_HIP(ctx->qa.ensure(NP * S * 4));
+    FS_HIP(ctx->qb.ensure(NO * S * 4));
+    FS_HIP(ctx->unary.ensure(NO * S * 4));
+    FS_HIP(ctx->pot.ensure(NO * S * 4));
+    FS_HIP(ctx->f1.ensure(NP * 3 * 4));      // f1 | f4 share this buffer: 1 + 2 floats per pixel
+    FS_HIP(ctx->f2.ensure(NP * 2 * 4));
+    FS_HIP(ctx->f3.ensure(NP * 3 * 4));
+    float *d_f1 = ctx->f1.as<float>(), *d_f4 = d_f1 + NP;
+    for (int b = 0; b < B; ++b) {
+        FS_HIP(hipMemcpyAsync(ctx->qa.p, Q + (size_t)b * NP * S, NP * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->unary.p, unary + (size_t)b * NO * S, NO * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(d_f1, f1 + (size_t)b * NP, NP * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->f2.p, f2 + (size_t)b * NP * 2, NP * 2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->f3.p, f3 + (size_t)b * NP * 3, NP * 3 * 4, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipMemcpyAsync(d_f4, f4 + (size_t)b * NP * 2, NP * 2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_crf_lr_explicit(ctx->unary.as<float>(), ctx->qa.as<float>(), d_f1, ctx->f2.as<float>(), ctx->f3.as<float>(), d_f4,
+                               ctx->params.lr_coef, ctx->params.bias, ctx->params.weight, ctx->params.evidence, ctx->qb.as<float>(),
+                               potentials ? ctx->pot.as<float>() : nullptr, h, w, r, S, ctx->stream);
+        FS_HIP(hipGetLastError());
+        FS_HIP(hipMemcpyAsync(out + (size_t)b * NO * S, ctx->qb.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (potentials) FS_HIP(hipMemcpyAsync(potentials + (size_t)b * NO * S, ctx->pot.p, NO * S * 4, hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;

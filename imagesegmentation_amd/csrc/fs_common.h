@@ -32,6 +32,11 @@ struct CrfParams {
     float t12, t22, t32;   // squared thetas of the depth term
     float t23, t33;        // squared thetas of colour / angle terms
     float weight;
+    float evidence = 0.00005f;   // message added to the last ("unassigned") label: 0.00005 (find_surfaces.py:356-357, 451-452)
+    // mode 1: logistic-regression similarity of conv_crf_LR (find_surfaces.py:371-434) instead of the Gaussian kernels;
+    // then lr_coef = (depth, angle, colour, position) weights, bias = intercept + 4, evidence = auxiliary weight
+    int mode = 0;
+    float lr_coef[4] = {0.f, 0.f, 0.f, 0.f};
 };
 
 constexpr int kMaxLabels = 512;       // label channels S = num_surfaces + 1 of a frame (multiple of 32)
@@ -136,7 +141,11 @@ void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int til
 enum { CRF_LAST = 1, CRF_FIRST = 2 };
 // one mean-field update of nframes frames whose per-tile channel count fits `channel_class`
 hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
-                           int mode, hipStream_t st);
+                           float evidence, int mode, hipStream_t st);
+// conv_crf_LR.predict for one tile on explicit pixel-major tensors (device pointers)
+void launch_crf_lr_explicit(const float *unary, const float *Q, const float *f1, const float *f2, const float *f3, const float *f4,
+                            const float coef[4], float bias, float weight, float aux, float *out, float *potentials, int h, int w,
+                            int r, int S, hipStream_t st);
 // same update with the similarity evaluated in the kernel from descs[].featA / featB (no similarity planes);
 // wtab = per-offset weights [(2r+1)^2][4] = (w1', w2', w3', 0)
 int crf_fused_tile_height(int r);        // 16 or 8 rows (tile width 32), 0 if the window is too large for the fused kernel

@@ -162,6 +162,71 @@ __global__ __launch_bounds__(256) void crf_sim_explicit_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------
+// conv_crf_LR.predict on explicit feature tensors (operator-level API, find_surfaces.py:371-434):
+// one thread per output pixel, pixel-major tensors as the reference passes them.  The similarity
+// divides by the centre pixel's depth, so it is not symmetric and the half-window planes above
+// do not apply; this direct form is for interface completeness, the fused kernel is the fast path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void crf_lr_explicit_kernel(const float *__restrict__ unary, const float *__restrict__ Q,
+                                                              const float *__restrict__ f1, const float *__restrict__ f2,
+                                                              const float *__restrict__ f3, const float *__restrict__ f4,
+                                                              float4 coef, float bias, float weight, float aux,
+                                                              float *__restrict__ out, float *__restrict__ potentials, int h, int w,
+                                                              int r, int S)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 4 + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const int wp = w + 2 * r, k = 2 * r + 1;
+    const size_t ci = (size_t)(y + r) * wp + (x + r), oi = (size_t)y * w + x;
+    const float nd = 6.0f, na = 2.0f, nc = (float)(1.0 / 50.0), np_ = (float)(1.0 / 40.0);
+    // total of all messages first, then label by label (the window is re-read per label: S is small here)
+    float total = 0.0f, total_lo = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        float mx = -INFINITY;
+        for (int l = 0; l < S; ++l) {
+            float m = 0.0f;
+            for (int wy = 0; wy < k; ++wy)
+                for (int wx = 0; wx < k; ++wx) {
+                    if (wy == r && wx == r) continue;
+                    const size_t ji = (size_t)(y + wy) * wp + (x + wx);
+                    const float ql = Q[ji * S + l];
+                    if (ql == 0.0f) continue;
+                    const float d1 = div_no_nan(f1[ji] - f1[ci], f1[ci]);
+                    const float s1 = sqrtf(d1 * d1) * nd;
+                    const float a0 = f2[2 * ji] - f2[2 * ci], a1 = f2[2 * ji + 1] - f2[2 * ci + 1];
+                    const float s2 = sqrtf(a0 * a0 + a1 * a1) * na;
+                    const float e0 = f3[3 * ji] - f3[3 * ci], e1 = f3[3 * ji + 1] - f3[3 * ci + 1], e2 = f3[3 * ji + 2] - f3[3 * ci + 2];
+                    const float s3 = sqrtf((e0 * e0 + e1 * e1) + e2 * e2) * nc;
+                    const float p0 = f4[2 * ji] - f4[2 * ci], p1 = f4[2 * ji + 1] - f4[2 * ci + 1];
+                    const float s4 = sqrtf(p0 * p0 + p1 * p1) * np_;
+                    const float lr = bias + (((coef.x * s1 + coef.y * s2) + coef.z * s3) + coef.w * s4);
+                    m = m + lr * ql;
+                }
+            if (l == S - 1) m = m + aux;
+            if (pass == 0) {                         // compensated total, so that total - m keeps relative accuracy
+                const float t = total + m, bp = t - total;
+                total_lo += (total - (t - bp)) + (m - bp);
+                total = t;
+            } else {
+                const float add = unary[oi * S + l] + weight * ((total - m) + total_lo);
+                if (potentials) potentials[oi * S + l] = add;
+                out[oi * S + l] = -add;
+                mx = fmaxf(mx, -add);
+            }
+        }
+        if (pass == 1) {
+            float den = 0.0f;
+            for (int l = 0; l < S; ++l) {
+                const float e = expf(out[oi * S + l] - mx);
+                out[oi * S + l] = e;
+                den = den + e;
+            }
+            for (int l = 0; l < S; ++l) out[oi * S + l] = out[oi * S + l] / den;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // initial probabilities, get_unary_potentials_and_initial_probabilities
 // (find_surfaces.py:456-477): double arithmetic, cast to float like Keras does.
 // Writes label planes Q[l][p] of every frame of the launch (blockIdx.y = frame).
@@ -325,19 +390,20 @@ __device__ __forceinline__ void stage_q(float4 *lds4, const int *s_list, const f
 // m[c] = message of channel c (c < CE).
 template <int NC, bool COMPACT>
 __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, const CrfFrameDesc &d, int S, size_t No,
-                                             size_t wi, unsigned p, bool invalid, float weight, int last)
+                                             size_t wi, unsigned p, bool invalid, float weight, float evidence, int last)
 {
     const int CE = s_list[0], n_rest = s_list[1], rep_pos = s_list[2];
     const float pv = (float)(1.0 / (double)(S - 1));
     const int own = d.patches ? d.patches[p] : 0;
-    // evidence of the constant "unassigned" input: 0.00005 * onehot(S-1)   (find_surfaces.py:356-357, 451-452)
+    // evidence of the constant "unassigned" input: evidence * onehot(S-1), 0.00005 for the Gaussian similarity
+    // (find_surfaces.py:356-357, 451-452), the auxiliary weight for the logistic-regression one (:424-425)
     // total over all S labels (the representative counts n_rest times), compensated so that
     // compatibility[l] = total - msg[l] keeps full relative accuracy
     float tot = 0.0f, tot_lo = 0.0f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < CE) {
-            if (c == CE - 1) m[c] = m[c] + 0.00005f;
+            if (c == CE - 1) m[c] = m[c] + evidence;
             const float term = c == rep_pos ? m[c] * (float)n_rest : m[c];
             const float t = tot + term;
             const float bp = t - tot;
@@ -399,7 +465,7 @@ __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, 
 // ---------------------------------------------------------------------------
 template <int R, int PY, int NCH>
 __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g,
-                                                                 float weight, int last)
+                                                                 float weight, float evidence, int last)
 {
     constexpr int CH = 8;                     // channels staged per pass
     constexpr int NW = ITH / PY;              // waves per block
@@ -500,7 +566,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        finish_pixel<NCH * CH, false>(m, s_list, d, S, No, wi[i], p[i], d.depth_raw && !valid[i], weight, last);
+        finish_pixel<NCH * CH, false>(m, s_list, d, S, No, wi[i], p[i], d.depth_raw && !valid[i], weight, evidence, last);
     }
 }
 
@@ -526,7 +592,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // On the first update Q is synthesised from the patch labels
 // (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
 // ---------------------------------------------------------------------------
-struct FusedConsts { float K1, K2, K3, C2, C3, bias; };
+struct FusedConsts { float K1, K2, K3, C2, C3, evidence; };
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
@@ -536,7 +602,7 @@ constexpr int FTW = 32;                       // tile width of the fused kernel
 // the pair that a neighbour row does not reach, so no masking is left in the loop.
 // The relative depth difference divides by (d_p + d_q): a lane whose own depth is 0 may produce
 // NaN here; its result is overridden afterwards (Q[depth == 0]) and never read.
-template <int R, int NQ>
+template <int R, int NQ, int MODE>
 __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float4 *lds4, int plane4, int LW, int trow, int col, int r,
                                                  const FusedConsts &K, const float4 *__restrict__ wtab)
 {
@@ -551,6 +617,8 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         cd = f2{a0.x, a1.x}; cr = f2{a0.y, a1.y}; cg = f2{a0.z, a1.z}; cb = f2{a0.w, a1.w};
         ca0 = f2{b0.x, b1.x}; ca1 = f2{b0.y, b1.y};
     }
+    const f2 cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
+    (void)cinv;
     // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i
     for (int jr = 0; jr < 2 + 2 * r; ++jr) {
         const int rowbase = (trow + jr) * LW + col;       // window column dx = -r (LDS offsets are unsigned)
@@ -570,23 +638,37 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
             if (NQ > 1) q1 = rowQ1[dx + r];
             const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
             const f2 dj = f2{fa.x, fa.x};
-            const f2 den = cd + dj;
-            const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            const f2 t = (dj - cd) * inv;
-            const f2 u = t * t;
             const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
             const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
             const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
             const f2 ea = __builtin_elementwise_fma(g1, g1, g0 * g0);
-            const f2 x1 = f2{K.K1, K.K1} * u;
-            const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
-            const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
-            const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
-            const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
-            const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
-            const f2 sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
-                          __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
-                          __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
+            f2 sv;
+            if (MODE == 0) {
+                // Gaussian kernels (find_surfaces.py:339-355); wtab = (w1', w2', w3', bias)
+                const f2 den = cd + dj;
+                const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const f2 t = (dj - cd) * inv;
+                const f2 u = t * t;
+                const f2 x1 = f2{K.K1, K.K1} * u;
+                const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
+                const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
+                const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
+                const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
+                const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
+                sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
+                     __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
+                     __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
+            } else {
+                // linear similarity (find_surfaces.py:406-422); wtab = (6 c1, 2 c2, c3 / 50, bias + c4 |offset| / 40);
+                // the depth difference is relative to the lane's own depth (cinv = 1 / d_p, 0 if d_p == 0)
+                const f2 t = (dj - cd) * cinv;
+                const f2 at = f2{__builtin_fabsf(t.x), __builtin_fabsf(t.y)};
+                const f2 sa = f2{__builtin_amdgcn_sqrtf(ea.x), __builtin_amdgcn_sqrtf(ea.y)};
+                const f2 sc = f2{__builtin_amdgcn_sqrtf(ec.x), __builtin_amdgcn_sqrtf(ec.y)};
+                sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, sc,
+                     __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
+                     __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float sI = i == 0 ? sv.x : sv.y;
@@ -605,7 +687,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
 }
 
-template <int R, int TH, int NCH>
+template <int R, int TH, int NCH, int MODE>
 __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last)
 {
@@ -735,8 +817,8 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
             __syncthreads();
             if (wave_work && FS_SKIPMAIN == 0) {
                 // 1..4 channels of the chunk need only the first quad plane (two thirds of all tiles)
-                if (CE - ch * CH <= 4) fused_accumulate<R, 1>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
-                else fused_accumulate<R, 2>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                if (CE - ch * CH <= 4) fused_accumulate<R, 1, MODE>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                else fused_accumulate<R, 2, MODE>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
             }
         }
     }
@@ -747,7 +829,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], p[i], !valid[i], weight, last);
+        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], p[i], !valid[i], weight, K.evidence, last);
     }
 }
 
@@ -763,7 +845,7 @@ __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *
 }
 
 template <int R, int PY, int NCH>
-hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, int last, hipStream_t st)
+hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, float evidence, int last, hipStream_t st)
 {
     static size_t attr_lds = 0;
     auto kern = crf_iter_kernel<R, PY, NCH>;
@@ -775,16 +857,16 @@ hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &
         attr_lds = lds;
     }
     dim3 grid((g.ow + ITW - 1) / ITW, (g.oh + ITH - 1) / ITH, nframes);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, last);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, evidence, last);
     return hipGetLastError();
 }
 
-template <int R, int TH, int NCH>
+template <int R, int TH, int NCH, int MODE>
 hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
                           float weight, int first, int last, hipStream_t st)
 {
     static size_t attr_lds = 0;                  // dynamic LDS the kernel has been allowed so far
-    auto kern = crf_iter_fused_kernel<R, TH, NCH>;
+    auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE>;
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
     const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8);
     if (lds + lds_static > 160 * 1024) return hipErrorInvalidValue;
@@ -799,6 +881,14 @@ hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom 
 }
 
 }  // namespace
+
+void launch_crf_lr_explicit(const float *unary, const float *Q, const float *f1, const float *f2, const float *f3, const float *f4,
+                            const float coef[4], float bias, float weight, float aux, float *out, float *potentials, int h, int w,
+                            int r, int S, hipStream_t st)
+{
+    hipLaunchKernelGGL(crf_lr_explicit_kernel, dim3((w + 31) / 32, (h + 3) / 4), dim3(128), 0, st, unary, Q, f1, f2, f3, f4,
+                       make_float4(coef[0], coef[1], coef[2], coef[3]), bias, weight, aux, out, potentials, h, w, r, S);
+}
 
 size_t crf_half_offsets(int r) { return (size_t)r + (size_t)r * (2 * r + 1); }
 size_t crf_sim_slack(int W, int r) { return (size_t)r * W + r; }
@@ -885,18 +975,29 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     FusedConsts K;
     K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
     K.C2 = (float)(P.t23 / 2500.0 * l2e); K.C3 = (float)(4.0 * P.t33 * l2e);
-    K.bias = P.bias;
+    K.evidence = P.evidence;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
     const int th = crf_fused_tile_height(g.r);
 #define FS_FUSED_CASES(RR, THH)                                                                              \
     switch (channel_class) {                                                                                 \
-    case 1: return launch_fused_t<RR, THH, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 2: return launch_fused_t<RR, THH, 2>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 1: return launch_fused_t<RR, THH, 1, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 2: return launch_fused_t<RR, THH, 2, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
     case 3:                                                                                                  \
-    case 4: return launch_fused_t<RR, THH, 4>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 8: return launch_fused_t<RR, THH, 8>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 16: return launch_fused_t<RR, THH, 16>(descs, nframes, g, K, wt, P.weight, first, last, st);       \
+    case 4: return launch_fused_t<RR, THH, 4, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 8: return launch_fused_t<RR, THH, 8, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 16: return launch_fused_t<RR, THH, 16, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);       \
     default: return hipErrorInvalidValue;                                                                    \
+    }
+    if (P.mode == 1) {
+        // logistic-regression similarity: two channel classes only (it is not the tuned path)
+        if (channel_class > 16) return hipErrorInvalidValue;
+        if (th == 16)
+            return channel_class <= 2 ? launch_fused_t<0, 16, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, st)
+                                      : launch_fused_t<0, 16, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);
+        if (th == 8)
+            return channel_class <= 2 ? launch_fused_t<0, 8, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, st)
+                                      : launch_fused_t<0, 8, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);
+        return hipErrorInvalidValue;
     }
     if (g.r == 7) { FS_FUSED_CASES(7, 16) }
     if (th == 16) { FS_FUSED_CASES(0, 16) }
@@ -906,31 +1007,31 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
 }
 
 hipError_t launch_crf_iter(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g, float weight,
-                           int mode, hipStream_t st)
+                           float evidence, int mode, hipStream_t st)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0;
     // accumulators are NCH x PY x 8 registers per lane: one row per lane when many channels are live
     if (g.r == 7) {
         switch (channel_class) {
-        case 1: return launch_iter_t<7, 2, 1>(descs, nframes, g, weight, last, st);
-        case 2: return launch_iter_t<7, 2, 2>(descs, nframes, g, weight, last, st);
-        case 3: return launch_iter_t<7, 2, 3>(descs, nframes, g, weight, last, st);
-        case 4: return launch_iter_t<7, 2, 4>(descs, nframes, g, weight, last, st);
-        case 8: return launch_iter_t<7, 2, 8>(descs, nframes, g, weight, last, st);
+        case 1: return launch_iter_t<7, 2, 1>(descs, nframes, g, weight, evidence, last, st);
+        case 2: return launch_iter_t<7, 2, 2>(descs, nframes, g, weight, evidence, last, st);
+        case 3: return launch_iter_t<7, 2, 3>(descs, nframes, g, weight, evidence, last, st);
+        case 4: return launch_iter_t<7, 2, 4>(descs, nframes, g, weight, evidence, last, st);
+        case 8: return launch_iter_t<7, 2, 8>(descs, nframes, g, weight, evidence, last, st);
         default: break;
         }
     } else {
         switch (channel_class) {
-        case 1: return launch_iter_t<0, 2, 1>(descs, nframes, g, weight, last, st);
-        case 2: return launch_iter_t<0, 2, 2>(descs, nframes, g, weight, last, st);
+        case 1: return launch_iter_t<0, 2, 1>(descs, nframes, g, weight, evidence, last, st);
+        case 2: return launch_iter_t<0, 2, 2>(descs, nframes, g, weight, evidence, last, st);
         case 3:
-        case 4: return launch_iter_t<0, 2, 4>(descs, nframes, g, weight, last, st);
-        case 8: return launch_iter_t<0, 2, 8>(descs, nframes, g, weight, last, st);
+        case 4: return launch_iter_t<0, 2, 4>(descs, nframes, g, weight, evidence, last, st);
+        case 8: return launch_iter_t<0, 2, 8>(descs, nframes, g, weight, evidence, last, st);
         default: break;
         }
     }
-    if (channel_class == 16) return launch_iter_t<0, 1, 16>(descs, nframes, g, weight, last, st);
+    if (channel_class == 16) return launch_iter_t<0, 1, 16>(descs, nframes, g, weight, evidence, last, st);
     return hipErrorInvalidValue;
 }
 

@@ -23,6 +23,7 @@ from .config import height, width, viewing_angle_x, viewing_angle_y, test_indice
 from .load_images import load_image, load_image_and_surface_information, sorted_alphanumeric  # noqa: F401
 
 similarity_normalizers = [6, 2, 1 / 50, 1 / 40]     # depth, angle, colour, position (find_surfaces.py:20)
+LR_CRF_parameters = [0.01, 15000]                    # weight, auxiliary weight (find_surfaces.py:22)
 standard_kernel_size = 7                             # find_surfaces.py:23
 div_x, div_y = 4, 4                                  # find_surfaces.py:24
 frames_per_call = 37                                 # frames handed to the GPU per call by find_surfaces_for_indices
@@ -49,7 +50,10 @@ def _context(h, w, kernel_size, max_batch=1, params=None):
     if ctx.kernel_size != kernel_size:
         ctx.set_kernel_size(kernel_size)
     if params is not None:
-        ctx.set_gauss_params(params)
+        if len(params) == 7:
+            ctx.set_lr_params(params)         # logistic-regression similarity
+        else:
+            ctx.set_gauss_params(params)
     return ctx
 
 
@@ -64,8 +68,10 @@ def load_Gauss_parameters():
 
 
 def load_pixel_similarity_parameters():
-    """Logistic-regression similarity (find_surfaces.py:216-218): not part of this build."""
-    raise NotImplementedError("the LR pixel-similarity CRF (mode='LR') is not built; use mode='Gauss'")
+    """(coef_ [1, 4], intercept_ + 4 [1]) of the logistic-regression pixel similarity
+    (find_surfaces.py:216-218), from the JSON copy of the shipped classifier's float64 values."""
+    p = _lib.lr_parameters()
+    return np.asarray([p[:4]], np.float64), np.asarray([p[4]], np.float64)
 
 
 # ---------------------------------------------------------------------------------------
@@ -132,6 +138,28 @@ class conv_crf_Gauss:
     __call__ = predict
 
 
+class conv_crf_LR:
+    """One mean-field update with the linear (logistic-regression) pixel similarity
+    (find_surfaces.py:371-434).  conv_crf_LR(LR_weights, LR_bias, weight, auxiliary_weight, kernel_size,
+    height, width).predict([unary, Q, f1 depth [..,1], f2 angles [..,2], f3 colour [..,3], f4 (row, col)
+    [..,2], val], batch_size=1) -> updated Q [B,h,w,S]."""
+
+    def __init__(self, LR_weights, LR_bias, weight, auxiliary_weight, kernel_size, height, width):
+        self.params = np.asarray(list(np.reshape(LR_weights, -1)) + [np.reshape(LR_bias, -1)[0], weight, auxiliary_weight],
+                                 np.float32)
+        self.kernel_size, self.height, self.width = int(kernel_size), int(height), int(width)
+
+    def predict(self, inputs, batch_size=1, want_potentials=False):
+        unary, Q, f1, f2, f3, f4, val = inputs
+        unary = np.asarray(unary, np.float32)
+        if unary.shape[1:3] != (self.height, self.width):
+            raise ValueError(f"model built for tiles of {self.height}x{self.width}, got {unary.shape[1:3]}")
+        ctx = _context(height, width, self.kernel_size, params=self.params)
+        return ctx.crf_step_lr(unary, Q, f1, f2, f3, f4, val, want_potentials=want_potentials)
+
+    __call__ = predict
+
+
 class _Models(tuple):
     """The 4-tuple get_GPU_models() returns; carrying the settings lets find_surfaces()
     take the fused path."""
@@ -143,9 +171,10 @@ def get_GPU_models(mode="LR", kernel_size=standard_kernel_size):
     """-> (smoothing_model, surface_model, normals_model, crf_model) (find_surfaces.py:26-32)."""
     size_x, size_y = int(width / div_x), int(height / div_y)
     if mode == "LR":
-        load_pixel_similarity_parameters()
-    models = _Models((_SmoothingModel(kernel_size), _SurfaceModel(kernel_size), _NormalsModel(kernel_size),
-                      conv_crf_Gauss(*load_Gauss_parameters(), kernel_size, size_y, size_x)))
+        crf = conv_crf_LR(*load_pixel_similarity_parameters(), *LR_CRF_parameters, kernel_size, size_y, size_x)
+    else:
+        crf = conv_crf_Gauss(*load_Gauss_parameters(), kernel_size, size_y, size_x)
+    models = _Models((_SmoothingModel(kernel_size), _SurfaceModel(kernel_size), _NormalsModel(kernel_size), crf))
     models.mode, models.kernel_size = mode, kernel_size
     return models
 
@@ -218,7 +247,7 @@ def _grid(h, w):
 # ---------------------------------------------------------------------------------------
 # the stage
 # ---------------------------------------------------------------------------------------
-def _find_surfaces_operators(models, data, kernel_size):
+def _find_surfaces_operators(models, data, kernel_size, mode="Gauss"):
     """The body of the reference's find_surfaces() (find_surfaces.py:499-532) over the four
     model objects, tile by tile."""
     smoothing_model, surface_model, normals_model, crf_model = models
@@ -227,7 +256,10 @@ def _find_surfaces_operators(models, data, kernel_size):
     grid = _grid(h, w)
     smoothed = smoothing_model(data["depth"], grid)
     data["angles"], data["vectors"], data["points_3d"] = normals_model(smoothed)
-    features = extract_features(data["depth"], data["rgb"], data["angles"], grid)
+    if mode == "LR":
+        features = [np.expand_dims(data["depth"], axis=-1), data["angles"], data["rgb"], grid]     # find_surfaces.py:508-509
+    else:
+        features = extract_features(data["depth"], data["rgb"], data["angles"], grid)
     data["patches"], data["depth_edges"] = surface_model(smoothed)
     data["num_surfaces"] = int(np.max(data["patches"]) + 1)
     unary, Q, prob = get_unary_potentials_and_initial_probabilities(data)
@@ -246,8 +278,6 @@ def find_surfaces(models, image_data, mode, kernel_size, plot_result=False, save
     rgb uint8 [H,W,3], annotation); returns the dict with keys depth, rgb, annotation, angles,
     vectors, points_3d, patches, depth_edges, num_surfaces, surfaces and, with save_index >= 0,
     writes out/{save_index}/*.npy."""
-    if mode == "LR":
-        load_pixel_similarity_parameters()
     data = {}
     data["depth"], data["rgb"], data["annotation"] = image_data
     if isinstance(models, _Models):
@@ -257,7 +287,7 @@ def find_surfaces(models, image_data, mode, kernel_size, plot_result=False, save
         for k in ("angles", "vectors", "points_3d", "patches", "depth_edges", "num_surfaces", "surfaces"):
             data[k] = res[k]
     else:
-        _find_surfaces_operators(models, data, kernel_size)
+        _find_surfaces_operators(models, data, kernel_size, mode)
     if plot_result:
         from .plot_image import plot_surfaces
         plot_surfaces(data["surfaces"])

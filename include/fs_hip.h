@@ -43,6 +43,12 @@ int fs_set_view_angles(fs_ctx *ctx, double view_x, double view_y);
  * (find_surfaces.py:291).  Thetas are squared inside, as the graph does (:339-341). */
 int fs_set_gauss_params(fs_ctx *ctx, const float params[13]);
 
+/* Switches the CRF to the logistic-regression pixel similarity of conv_crf_LR (find_surfaces.py:371-434,
+ * find_surfaces(mode="LR")): p = coef[0..3] (weights of the depth, angle, colour and position distances,
+ * clf.coef_), bias (clf.intercept_ + 4, load_pixel_similarity_parameters, :216-218), weight and
+ * auxiliary_weight (LR_CRF_parameters, :22).  fs_set_gauss_params() switches back. */
+int fs_set_lr_params(fs_ctx *ctx, const float params[7]);
+
 /* CRF window radius, the kernel_size argument of conv_crf_Gauss / find_surfaces
  * (find_surfaces.py:23, 291, 497); default 7, at most 15. */
 int fs_set_kernel_size(fs_ctx *ctx, int kernel_size);
@@ -89,9 +95,15 @@ int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_siz
 int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, const float *Q, const float *f1,
                 const float *f2, const float *f3, const float *val, float *out, float *potentials);
 
+/* conv_crf_LR(...).predict([unary, Q, f1, f2, f3, f4, val], batch_size=1) (find_surfaces.py:371-434):
+ * f1 [B][h+2r][w+2r][1] depth, f2 [..][2] angles, f3 [..][3] colour, f4 [..][2] (row, col); the rest as
+ * fs_crf_step.  Needs fs_set_lr_params(). */
+int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, const float *Q, const float *f1,
+                   const float *f2, const float *f3, const float *f4, const float *val, float *out, float *potentials);
+
 /* ---- fused path: find_surfaces() for a batch of frames ---------------------
- * find_surfaces(models, image_data, "Gauss", kernel_size) (find_surfaces.py:497-
- * 532) for n frames: depth uint16 [n][H][W], rgb uint8 [n][H][W][3] ->
+ * find_surfaces(models, image_data, mode, kernel_size) (find_surfaces.py:497-
+ * 532) for n frames, mode "Gauss" or "LR" according to the parameters set last: depth uint16 [n][H][W], rgb uint8 [n][H][W][3] ->
  * the arrays of the returned dict / of the out/{index} .npy files (:537-545):
  * angles, vectors, points_3d, patches, depth_edges, surfaces ("Q.npy"),
  * num_surfaces[n] = max(patches)+1.  Any output pointer may be NULL. */

@@ -245,3 +245,63 @@ def surface_stats(surfaces, patches, depth_edges, points_3d, angles, lab, textur
     out.update(surfaces=surf, avg_pos=avg, counts=cnt, centroids=cen, centroid_indices=cidx, hist_color=hc, hist_angle=ha,
                hist_texture=ht, avg_angles=aa, neighbor_counts=nb, border_centers=bc, norm=norm, depth_extend=de)
     return out
+
+
+# ---------------------------------------------------------------------------
+# logistic-regression similarity (fs_oracle_lr.c; find_surfaces.py:371-434)
+# ---------------------------------------------------------------------------
+def lr_params():
+    """(coef[4], intercept + 4, weight 0.01, auxiliary weight 15000): load_pixel_similarity_parameters
+    (find_surfaces.py:216-218) and LR_CRF_parameters (:22), from the JSON copy of the shipped values."""
+    import json
+    path = os.path.join(os.path.dirname(_HERE), "imagesegmentation_amd", "params", "lr.json")
+    with open(path) as f:
+        doc = json.load(f)
+    return np.asarray(list(doc["coef"]) + [doc["intercept"] + 4, 0.01, 15000], np.float32)
+
+
+def crf_step_lr(unary, Q, f1, f2, f3, f4, val, params, r, want_potentials=False):
+    unary, Q = _c(unary, np.float32), _c(Q, np.float32)
+    f1, f2, f3, f4 = (_c(f, np.float32) for f in (f1, f2, f3, f4))
+    B, h, w, S = unary.shape
+    val = _c(np.asarray(val, np.float32).reshape(-1, S)[0], np.float32)
+    params = _c(np.asarray(params).reshape(-1), np.float32)
+    out = np.empty((B, h, w, S), np.float32)
+    pot = np.empty((B, h, w, S), np.float32) if want_potentials else None
+    lib().fso_crf_step_lr(_p(unary), _p(Q), _p(f1), _p(f2), _p(f3), _p(f4), _p(val), _p(params), r, h, w, S, B, _p(out), _p(pot))
+    return (out, pot) if want_potentials else out
+
+
+def crf_frame_lr(unary, Q, depth_raw, rgb, angles, params, r, want_potentials=False):
+    unary, Q = _c(unary, np.float32), _c(Q, np.float32)
+    H, W, S = unary.shape
+    d, c, a = _c(depth_raw, np.uint16), _c(rgb, np.uint8), _c(angles, np.float32)
+    params = _c(np.asarray(params).reshape(-1), np.float32)
+    out = np.empty((H, W, S), np.float32)
+    pot = np.empty((H, W, S), np.float32) if want_potentials else None
+    lib().fso_crf_frame_lr(_p(unary), _p(Q), _p(d), _p(c), _p(a), _p(params), r, H, W, S, _p(out), _p(pot))
+    return (out, pot) if want_potentials else out
+
+
+def find_surfaces_lr(depth_raw, rgb, params, r=7, iterations=3, want_q=False):
+    """find_surfaces(mode="LR") (find_surfaces.py:497-532): the Gauss pipeline with the CRF update swapped."""
+    d, c = _c(depth_raw, np.uint16), _c(rgb, np.uint8)
+    H, W = d.shape
+    sm = smooth_depth(d.astype(np.float32))
+    pts, vec, raw = normals(sm)
+    ang = angle_filter(raw, sm)
+    pat, edges = patches(sm)
+    ns = int(pat.max()) + 1
+    unary, Q, prob = unary_q0(pat, ns)
+    for it in range(iterations):
+        Q = crf_frame_lr(unary, Q, d, c, ang, params, r)
+        if it == iterations - 1 and want_q:
+            qf = Q.copy()
+        Q[d == 0] = prob.reshape(-1) if it < iterations - 1 else 0
+    surf = np.argmax(Q, axis=-1).astype(np.int64)
+    surf[surf == ns] = 0
+    out = {"angles": ang, "vectors": vec, "points_3d": pts, "patches": pat, "depth_edges": edges, "surfaces": surf,
+           "smoothed": sm, "num_surfaces": ns}
+    if want_q:
+        out["q_final"] = qf
+    return out

@@ -289,6 +289,49 @@ def conv_crf_gauss_predict(inputs, params, kernel_size, want_potentials=False):
     return (np.asarray(outs), np.asarray(pots)) if want_potentials else np.asarray(outs)
 
 
+def conv_crf_lr_predict(inputs, params, kernel_size, want_potentials=False):
+    """find_surfaces.py:371-434 (conv_crf_LR), batch_size=1 semantics; params = coef[4], bias, weight, aux."""
+    unary_b, Q_b, f1_b, f2_b, f3_b, f4_b, val_b = inputs
+    c = [f32(v) for v in np.asarray(params).reshape(-1)]
+    coef, bias, weight, aux = np.asarray(c[:4], f32), c[4], c[5], c[6]
+    r, k = kernel_size, 2 * kernel_size + 1
+    norms = [f32(6), f32(2), f32(1 / 50), f32(1 / 40)]
+    outs, pots = [], []
+    for b in range(len(unary_b)):
+        unary, Q = np.asarray(unary_b[b], f32), np.asarray(Q_b[b], f32)
+        feats = [np.asarray(f[b], f32) for f in (f1_b, f2_b, f3_b, f4_b)]
+        val = np.asarray(val_b[b], f32).reshape(-1)
+        h, w, S = unary.shape
+
+        def windows(a):                                             # [h,w,k,k,C]
+            return np.moveaxis(sliding_window_view(a, (k, k), (0, 1)), 2, -1)
+
+        mask = np.ones((k, k, 1), f32)
+        mask[r, r, 0] = 0
+        wq = windows(Q) * mask
+        sims = []
+        for i, f in enumerate(feats):
+            wf = windows(f)
+            feature = np.tile(wf[:, :, r:r + 1, r:r + 1, :], [1, 1, k, k, 1])
+            diff = wf - feature
+            if i == 0:
+                diff = divide_no_nan(diff, feature)
+            sims.append(np.sqrt(_seq_sum(np.square(diff))).astype(f32) * norms[i])
+        sim = np.stack(sims, axis=-1).reshape(h, w, k * k, 4)
+        lr = bias + _seq_sum(coef * sim)
+        concat = np.concatenate([lr, np.ones((h, w, 1), f32) * aux], axis=-1)
+        wq = np.concatenate([wq.reshape(h, w, k * k, S), np.tile(val.reshape(1, 1, 1, S), [h, w, 1, 1])], axis=-2)
+        messages = _seq_sum(concat[..., None] * wq, axis=-2)
+        matrix = (np.ones((S, S), f32) - np.eye(S, dtype=f32))
+        compat = _seq_sum(matrix[None, None] * np.tile(messages[:, :, None, :], [1, 1, S, 1]))
+        add = unary + weight * compat
+        logits = -add
+        e = np.exp(logits - logits.max(-1, keepdims=True)).astype(f32)
+        outs.append(e / _seq_sum(e)[..., None])
+        pots.append(add)
+    return (np.asarray(outs), np.asarray(pots)) if want_potentials else np.asarray(outs)
+
+
 def find_surfaces(depth, rgb, params, kernel_size=7, div_x=4, div_y=4, view_x=VIEW_X, view_y=VIEW_Y):
     """find_surfaces.py:497-532, including the reference's 4x4 tiling."""
     depth = np.asarray(depth)

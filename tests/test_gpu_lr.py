@@ -1,0 +1,82 @@
+"""GPU parity of the logistic-regression CRF variant (conv_crf_LR, find_surfaces(mode="LR")) against
+the C oracle (oracle/fs_oracle_lr.c): potentials within 1e-4 relative, probabilities within 2e-5
+absolute, labels equal except numerical ties."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+# a parameter set whose result is not trivially "everything unassigned" (the shipped auxiliary weight of
+# 15000 puts all probability on the last label)
+SOFT = np.asarray([-3.4754366, -1.1483647, -4.0971241, 1.3293620, 1.5, 0.01, 0.5], np.float32)
+
+
+def _inputs(g, r):
+    from oracle import oracle as O
+    depth, rgb, ang = g["depth"], g["rgb"], g["angles"]
+    H, W = depth.shape
+    ns = int(g["num_surfaces"])
+    unary, q0, _ = O.unary_q0(g["patches"].astype(np.int64), ns)
+    grid = np.stack(np.meshgrid(np.arange(H), np.arange(W), indexing="ij"), -1).astype(np.float32)
+    pad = lambda a: np.pad(a.astype(np.float32), [[r, r], [r, r], [0, 0]])[None]
+    val = np.zeros(ns + 1, np.float32)
+    val[-1] = 1
+    return unary[None], pad(q0), pad(depth[..., None]), pad(ang), pad(rgb), pad(grid), val
+
+
+@pytest.mark.parametrize("params", ["shipped", "soft"])
+def test_crf_step_lr_operator(oracle, params):
+    from imagesegmentation_amd._lib import Context
+    p = oracle.lr_params() if params == "shipped" else SOFT
+    g = np.load(os.path.join(GOLD, "synth_11.npz"))
+    inp = _inputs(g, 7)
+    with Context(96, 128, params=p) as ctx:
+        out, pot = ctx.crf_step_lr(*inp, want_potentials=True)
+    out_o, pot_o = oracle.crf_step_lr(*inp, p, 7, want_potentials=True)
+    # unary + weight * compatibility can cancel to ~0 here (messages are signed), so the error is
+    # measured against the size of the terms: |unary| <= 10 and |weight * compatibility| ~ |potential| + 1
+    rel = np.abs(pot - pot_o) / (np.abs(pot_o) + 1.0)
+    assert rel.max() <= 1e-4, rel.max()
+    assert np.abs(out - out_o).max() <= 2e-5
+
+
+@pytest.mark.parametrize("params", ["shipped", "soft"])
+def test_find_surfaces_lr_fused(oracle, params):
+    from imagesegmentation_amd._lib import Context
+    p = oracle.lr_params() if params == "shipped" else SOFT
+    for name in ("synth_12", "synth_13"):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        with Context(96, 128, params=p) as ctx:
+            got = ctx.find_surfaces_batch(g["depth"], g["rgb"])
+        ref = oracle.find_surfaces_lr(g["depth"], g["rgb"], p, want_q=True)
+        assert np.array_equal(got["patches"], ref["patches"])
+        dis = got["surfaces"] != ref["surfaces"]
+        if dis.any():
+            q = np.sort(ref["q_final"][dis], axis=-1)
+            assert ((q[:, -1] - q[:, -2]) <= 1e-5 * q[:, -1]).all(), name
+        assert dis.mean() <= 0.005
+        if params == "soft":
+            assert len(np.unique(ref["surfaces"])) > 3        # a non-trivial labelling
+
+
+def test_mirror_lr_mode(oracle):
+    """find_surface_model("LR") and the operator route through conv_crf_LR.predict."""
+    from imagesegmentation_amd import find_surfaces as fs
+    g = np.load(os.path.join(GOLD, "synth_12.npz"))
+    depth, rgb = g["depth"], g["rgb"]
+    H, W = depth.shape
+    fused = fs.find_surface_model("LR")((depth, rgb, None))
+    ref = oracle.find_surfaces_lr(depth, rgb, oracle.lr_params())
+    assert np.array_equal(fused["surfaces"], ref["surfaces"])
+    models = (fs._SmoothingModel(7), fs._SurfaceModel(7), fs._NormalsModel(7),
+              fs.conv_crf_LR(*fs.load_pixel_similarity_parameters(), *fs.LR_CRF_parameters, 7, H // fs.div_y, W // fs.div_x))
+    step = fs.find_surfaces(models, (depth, rgb, None), "LR", 7)
+    assert np.array_equal(step["surfaces"], ref["surfaces"])
+    # and back to the Gaussian similarity on the same context
+    gauss = fs.find_surface_model("Gauss")((depth, rgb, None))
+    assert (gauss["surfaces"] != g["surfaces"]).mean() <= 0.005

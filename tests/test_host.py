@@ -76,8 +76,12 @@ def test_load_gauss_parameters_shape():
     assert p[3][0, 0] == 0 and abs(p[12][0, 0] - 0.01) < 1e-9
     crf = fs.conv_crf_Gauss(*p, 7, 120, 160)
     assert crf.params.shape == (13,) and crf.kernel_size == 7
-    with pytest.raises(NotImplementedError):
-        fs.get_GPU_models("LR")
+    # logistic-regression variant: clf.coef_ [1,4], clf.intercept_ + 4 and LR_CRF_parameters
+    coef, bias = fs.load_pixel_similarity_parameters()
+    assert coef.shape == (1, 4) and bias.shape == (1,)
+    assert np.allclose(coef, [[-3.4754366, -1.1483647, -4.0971241, 1.3293620]]) and np.isclose(bias[0], 2.8543673 + 4)
+    lr = fs.get_GPU_models("LR")[3]
+    assert isinstance(lr, fs.conv_crf_LR) and lr.params.shape == (7,) and lr.params[6] == 15000
 
 
 # ------------------------------------------------------------------- loaders and file layout

@@ -119,6 +119,26 @@ def test_numpy_crf_update_matches_c_oracle(oracle):
     assert np.abs(Q - whole).max() <= 2e-6
 
 
+def test_numpy_lr_update_matches_c_oracle(oracle):
+    """conv_crf_LR: numpy windows vs C loops, shipped parameters and a softer set."""
+    from oracle import oracle_np as N
+    g = gold("synth_13")
+    depth, rgb = g["depth"], g["rgb"]
+    H, W = depth.shape
+    ns = int(g["num_surfaces"])
+    unary, q0, _ = N.get_unary_potentials_and_initial_probabilities(g["patches"].astype(np.int64), ns)
+    rows, cols = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    feats = [depth[..., None], g["angles"], rgb, np.stack([rows, cols], -1)]
+    r = 5
+    inputs = N.get_inputs(feats, unary, q0, r, 2, 2, W // 2, H // 2)
+    soft = np.asarray([-3.4754366, -1.1483647, -4.0971241, 1.3293620, 1.5, 0.01, 0.5], np.float32)
+    for params in (oracle.lr_params(), soft):
+        out_np, pot_np = N.conv_crf_lr_predict(inputs, params, r, want_potentials=True)
+        out_c, pot_c = oracle.crf_step_lr(*[np.asarray(a, np.float32) for a in inputs], params, r, want_potentials=True)
+        assert (np.abs(pot_np - pot_c) <= 1e-4 * (np.abs(pot_c) + 1)).all()
+        assert np.abs(out_np - out_c).max() <= 2e-5
+
+
 # ------------------------------------------------------------------- connected components
 def test_components_match_scipy_label(oracle):
     from scipy import ndimage
