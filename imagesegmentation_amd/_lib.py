@@ -39,6 +39,8 @@ SIGNATURES = {
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
+    "fs_chi_squared_distances": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "fs_set_timing": (_i, [_vp, _i]),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
 }
@@ -299,6 +301,23 @@ class Context:
                  "depth_extend")
         self._check(self._lib.fs_surface_stats(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
                                                _ptr(angles), _ptr(lab), _ptr(texture), T, *(_ptr(out[k]) for k in order)))
+        return out
+
+    def chi_squared_distances(self, hist, pool_size=(1, 1), strides=(1, 1)):
+        hist = _arr(hist, np.float64)
+        if hist.ndim == 2:                       # 1-D model: [K, S]
+            hist = hist[None]
+        A, B, S = hist.shape
+        out = np.empty((S, S), np.float32)
+        self._check(self._lib.fs_chi_squared_distances(self._h, _ptr(hist), A, B, S, int(pool_size[0]), int(pool_size[1]),
+                                                       int(strides[0]), int(strides[1]), _ptr(out)))
+        return out
+
+    def overlap_counts(self, annotation, detected, num_annotations, num_detections):
+        a = _arr(annotation, np.int64, (self.H, self.W))
+        o = _arr(detected, np.int64, (self.H, self.W))
+        out = np.empty((int(num_detections), int(num_annotations)))
+        self._check(self._lib.fs_overlap_counts(self._h, _ptr(a), _ptr(o), int(num_annotations), int(num_detections), _ptr(out)))
         return out
 
     def apply_crf(self, labels, depth, rgb, angles):

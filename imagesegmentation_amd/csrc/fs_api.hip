@@ -905,4 +905,52 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
     return 0;
 }
 
+int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int S, int pool_h, int pool_w, int stride_h, int stride_w,
+                             float *out)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (!hist || !out || A < 1 || B < 1 || S < 1 || pool_h < 1 || pool_w < 1 || stride_h < 1 || stride_w < 1 || pool_h > A || pool_w > B)
+        return ctx->fail("fs_chi_squared_distances: bad shape");
+    if (S > 65535) return ctx->fail("fs_chi_squared_distances: too many surfaces");
+    const int PA = (A - pool_h) / stride_h + 1, PB = (B - pool_w) / stride_w + 1;
+    const size_t in_bytes = (size_t)A * B * S * 8, pooled_bytes = (size_t)S * PA * PB * 4, out_bytes = (size_t)S * S * 4;
+    FS_HIP(ctx->st_in.ensure(in_bytes));
+    FS_HIP(ctx->st_scratch.ensure(pooled_bytes));
+    FS_HIP(ctx->st_out.ensure(out_bytes));
+    FS_HIP(hipMemcpyAsync(ctx->st_in.p, hist, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_chi_squared(ctx->st_in.as<double>(), ctx->st_scratch.as<float>(), ctx->st_out.as<float>(), A, B, S, pool_h, pool_w, stride_h,
+                       stride_w, ctx->stream);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(out, ctx->st_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *detected, int num_annotations, int num_detections,
+                      double *overlap)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (!annotation || !detected || !overlap || num_annotations < 1 || num_detections < 1)
+        return ctx->fail("fs_overlap_counts: bad arguments");
+    const size_t N = ctx->N(), cells = (size_t)num_annotations * num_detections;
+    FS_HIP(ctx->st_in.ensure(2 * N * 8));
+    FS_HIP(ctx->st_out.ensure(cells * 4 + 8));
+    int64_t *d_a = ctx->st_in.as<int64_t>(), *d_o = d_a + N;
+    unsigned *d_ov = ctx->st_out.as<unsigned>();
+    int *d_err = reinterpret_cast<int *>(d_ov + cells);
+    FS_HIP(hipMemcpyAsync(d_a, annotation, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(d_o, detected, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemsetAsync(d_ov, 0, cells * 4 + 8, ctx->stream));
+    launch_overlap_counts(d_a, d_o, d_ov, d_err, (int)N, num_detections, num_annotations, ctx->stream);
+    FS_HIP(hipGetLastError());
+    std::vector<unsigned> host(cells + 1);
+    FS_HIP(hipMemcpyAsync(host.data(), d_ov, cells * 4 + 4, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    if (host[cells]) return ctx->fail("fs_overlap_counts: a label lies outside the given counts");
+    for (size_t i = 0; i < cells; ++i) overlap[i] = (double)host[i];
+    return 0;
+}
+
 }  // extern "C"

@@ -100,6 +100,12 @@ struct StatsOut {
 size_t stats_sort_temp_bytes(int N);
 size_t stats_work_bytes(int S, int T);
 hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const StatsOut &out, int H, int W, int S, int T, hipStream_t st);
+// pairwise reductions (k_pairs.hip); device pointers.  pooled: S * PA * PB floats of scratch, out [S][S]
+void launch_chi_squared(const double *hist, float *pooled, float *out, int A, int B, int S, int ph, int pw, int sh, int sw,
+                        hipStream_t st);
+// overlap[nd][na] (zeroed by the caller) += 1 per pixel; *err = 1 if a label is out of range
+void launch_overlap_counts(const int64_t *annotation, const int64_t *detected, unsigned *overlap, int *err, int N, int nd, int na,
+                           hipStream_t st);
 // CRF (k_crf.hip)
 struct CrfFrameDesc {            // one frame of a batched launch (device-resident array of these)
     const float *sim0;           // similarity plane 0 of the frame (slack lies in front of it)

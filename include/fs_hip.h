@@ -152,6 +152,21 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
                      double *hist_color, double *hist_angle, double *hist_texture, double *avg_angles, double *neighbors,
                      double *border_centers, float *norm, float *depth_extend);
 
+/* chi_squared_distances_model_2D(pool_size, strides) (image_processing_models_GPU.py:189-200) applied to
+ * one histogram stack: hist float64 [A][B][S] (e.g. hist_color [256][256][S] with pool (10,10), strides
+ * (4,4), or hist_angle [40][40][S] with (4,4), (1,1): assemble_objects_rules.py:13-14) is cast to float32,
+ * average-pooled (VALID), and out float32 [S][S] receives sum over bins of divide_no_nan((a-b)^2, a+b).
+ * chi_squared_distances_model_1D (:202-212) on hist [K][S] is the call with A = 1, B = K, pool and
+ * strides 1. */
+int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int S, int pool_h, int pool_w,
+                             int stride_h, int stride_w, float *out);
+
+/* The pixel loop of evaluate_models.extract_IoU_information (evaluate_models.py:28-35): overlap float64
+ * [num_detections][num_annotations] = number of pixels with (detected == o, annotation == a); the row and
+ * column sums are the two count vectors of :33-34.  int64 [H][W] inputs, host pointers. */
+int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *detected, int num_annotations,
+                      int num_detections, double *overlap);
+
 /* ---- instrumentation -------------------------------------------------------
  * group_mask bit g set: HIP events are recorded on the context's stream around
  * every launch of kernel group g; fs_get_timing() synchronises and returns the

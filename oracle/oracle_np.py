@@ -356,3 +356,38 @@ def find_surfaces(depth, rgb, params, kernel_size=7, div_x=4, div_y=4, view_x=VI
     data["surfaces"][data["surfaces"] == data["num_surfaces"]] = 0
     data["smoothed"] = smoothed
     return data
+
+
+def chi_squared_distances(hist, pool_size=(1, 1), strides=(1, 1)):
+    """image_processing_models_GPU.py:189-212 in float32: VALID average pooling of hist [A,B,S], then
+    sum over bins of divide_no_nan((a-b)^2, a+b) for every pair of surfaces -> [S,S]."""
+    h = np.asarray(hist, f32)
+    if h.ndim == 2:
+        h = h[None]
+    A, B, S = h.shape
+    ph, pw = pool_size
+    sh, sw = strides
+    win = sliding_window_view(h, (ph, pw), (0, 1))[::sh, ::sw]            # [PA,PB,S,ph,pw]
+    pool = (win.reshape(win.shape[:3] + (-1,)).sum(-1, dtype=f32) / f32(ph * pw)).astype(f32)
+    pool = np.moveaxis(pool, 2, 0)                                         # [S,PA,PB]
+    e1, e2 = pool[None, :], pool[:, None]
+    d = divide_no_nan(np.square(e1 - e2), e1 + e2)
+    return d.sum(-1, dtype=f32).sum(-1, dtype=f32)
+
+
+def iou_information(annotation, detected, threshold=0.2):
+    """evaluate_models.py:19-58 with plain loops replaced by bincount."""
+    a, o = np.asarray(annotation, np.int64), np.asarray(detected, np.int64)
+    nd, na = int(o.max()) + 1, int(a.max()) + 1
+    overlap = np.bincount((o * na + a).ravel(), minlength=nd * na).reshape(nd, na).astype(np.float64)
+    cd, ca = overlap.sum(1), overlap.sum(0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = overlap / (ca[None] + cd[:, None] - overlap)
+        dov = overlap.sum(-1) / cd
+    iou_max = np.zeros(na - 1)
+    for i in range(na - 1):
+        for j in range(nd):
+            if iou[j, i + 1] > iou_max[i]:
+                iou_max[i] = iou[j, i + 1]
+    dov[np.isnan(dov)] = 0
+    return float((ca != 0).sum()), float((dov > threshold).sum()), iou_max, overlap
