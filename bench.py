@@ -114,9 +114,19 @@ def main():
     d_edges = torch.empty((n, H, W), dtype=torch.int32, device=dev)
     d_surfaces = torch.empty((n, H, W), dtype=torch.int64, device=dev)
 
+    host_out = [None]
+    if args.host_buffers:
+        # a caller after throughput keeps its frames in page-locked memory (imagesegmentation_amd._lib.pinned_empty)
+        from imagesegmentation_amd._lib import pinned_empty
+        pd, pc = pinned_empty(depth.shape, np.uint16), pinned_empty(rgb.shape, np.uint8)
+        pd[...] = depth
+        pc[...] = rgb
+        depth, rgb = pd, pc
+
     def step():
         if args.host_buffers:
-            return ctx.find_surfaces_batch(depth, rgb)["num_surfaces"]
+            host_out[0] = ctx.find_surfaces_batch(depth, rgb, out=host_out[0])     # page-locked outputs, reused
+            return host_out[0]["num_surfaces"]
         return ctx.find_surfaces_batch_dev(n, d_depth.data_ptr(), d_rgb.data_ptr(), d_angles.data_ptr(), d_vectors.data_ptr(),
                                            d_points.data_ptr(), d_patches.data_ptr(), d_edges.data_ptr(), d_surfaces.data_ptr())
 

@@ -36,6 +36,8 @@ SIGNATURES = {
     "fs_crf_step": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_crf_step_lr": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
+    "fs_host_alloc": (_vp, [_c.c_size_t]),
+    "fs_host_free": (None, [_vp]),
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
@@ -80,6 +82,32 @@ def lr_parameters():
     with open(os.path.join(_HERE, "params", "lr.json")) as f:
         doc = json.load(f)
     return np.asarray(list(doc["coef"]) + [doc["intercept"] + 4, 0.01, 15000], np.float32)
+
+
+class _PinnedBlock:
+    """Page-locked host allocation that lives as long as an array built on it."""
+
+    def __init__(self, nbytes):
+        self._lib = load()
+        self.ptr = self._lib.fs_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError(f"fs_host_alloc({nbytes}) failed")
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._lib.fs_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked memory (freed when the last view of it goes away)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    block = _PinnedBlock(n)
+    buf = (_c.c_char * max(n, 1)).from_address(block.ptr)
+    buf._block = block                    # the ctypes buffer is the array's base; it keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def _ptr(a):
@@ -242,21 +270,24 @@ class Context:
         return (out, pot) if want_potentials else out
 
     # -- fused path --------------------------------------------------------------
-    def find_surfaces_batch(self, depth, rgb):
+    def find_surfaces_batch(self, depth, rgb, out=None):
         """depth uint16 [n,H,W], rgb uint8 [n,H,W,3] -> dict of batched arrays with the
-        keys of the dict find_surfaces() returns (find_surfaces.py:503-532)."""
+        keys of the dict find_surfaces() returns (find_surfaces.py:503-532).  `out`: a dict
+        returned by an earlier call with the same n, to be overwritten instead of allocating."""
         d, single = self._batch(depth)
         c, _ = self._batch(rgb, (3,))
         d, c = _arr(d, np.uint16), _arr(c, np.uint8)
         n = d.shape[0]
-        out = {
-            "angles": np.empty((n, self.H, self.W, 2), np.float32),
-            "vectors": np.empty((n, self.H, self.W, 3), np.float32),
-            "points_3d": np.empty((n, self.H, self.W, 3), np.float32),
-            "patches": np.empty((n, self.H, self.W), np.int64),
-            "depth_edges": np.empty((n, self.H, self.W), np.int32),
-            "surfaces": np.empty((n, self.H, self.W), np.int64),
-        }
+        # outputs live in page-locked memory: the downloads are DMA transfers overlapped with the kernels
+        shapes = {"angles": ((2,), np.float32), "vectors": ((3,), np.float32), "points_3d": ((3,), np.float32),
+                  "patches": ((), np.int64), "depth_edges": ((), np.int32), "surfaces": ((), np.int64)}
+        if out is None:
+            out = {k: pinned_empty((n, self.H, self.W) + tail, dt) for k, (tail, dt) in shapes.items()}
+        else:
+            out = {k: (out[k][None] if single else out[k]) for k in shapes}
+            for k, (tail, dt) in shapes.items():
+                if out[k].shape != (n, self.H, self.W) + tail or out[k].dtype != dt or not out[k].flags.c_contiguous:
+                    raise ValueError(f"out[{k!r}] does not fit this batch")
         ns = np.empty(n, np.int32)
         self._check(self._lib.fs_find_surfaces_batch(
             self._h, n, _ptr(d), _ptr(c), _ptr(out["angles"]), _ptr(out["vectors"]), _ptr(out["points_3d"]),

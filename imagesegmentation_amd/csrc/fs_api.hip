@@ -25,6 +25,8 @@ struct fs_ctx {
     bool have_params = false;
     CrfParams params{};
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t in_stream = nullptr, out_stream = nullptr;   // copy streams of the host-buffer entry point
+    std::vector<hipEvent_t> pipe_events;
     std::string err;
 
     // tables
@@ -410,6 +412,8 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(0); }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
@@ -432,6 +436,9 @@ void fs_destroy(fs_ctx *ctx)
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
+    if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
+    for (hipEvent_t e : ctx->pipe_events) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -717,22 +724,64 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                            float *points, int64_t *patches, int32_t *edges, int64_t *surfaces, int32_t *num_surfaces)
 {
     if (check_batch(ctx, n)) return -1;
-    const size_t px = (size_t)n * ctx->N();
-    FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * ctx->N() * 2));
-    FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * ctx->N() * 3));
-    FS_HIP(hipMemcpyAsync(ctx->depth16.p, depth, px * 2, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, px * 3, hipMemcpyHostToDevice, ctx->stream));
-    if (fs_find_surfaces_batch_dev(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr, num_surfaces))
-        return -1;
-    if (angles) FS_HIP(hipMemcpyAsync(angles, ctx->angles.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (vectors) FS_HIP(hipMemcpyAsync(vectors, ctx->normals.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (points) FS_HIP(hipMemcpyAsync(points, ctx->points.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (patches) FS_HIP(hipMemcpyAsync(patches, ctx->patches64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (edges) FS_HIP(hipMemcpyAsync(edges, ctx->edges.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (surfaces) FS_HIP(hipMemcpyAsync(surfaces, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t N = ctx->N();
+    FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
+    FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
+    // Frames go through in chunks: the upload of chunk k+1 and the download of chunk k-1 run on their
+    // own streams beside the kernels of chunk k.  With pinned host memory (fs_host_alloc) the copies are
+    // true DMA transfers; with pageable memory the runtime stages them and the overlap is partial.
+    const int C = kCrfGroup;
+    const int chunks = (n + C - 1) / C;
+    while (ctx->pipe_events.size() < (size_t)2 * chunks) {
+        hipEvent_t e;
+        FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_events.push_back(e);
+    }
+    auto upload = [&](int k) -> int {
+        const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
+        FS_HIP(hipMemcpyAsync(ctx->depth16.as<uint16_t>() + f0 * N, depth + f0 * N, cn * N * 2, hipMemcpyHostToDevice, ctx->in_stream));
+        FS_HIP(hipMemcpyAsync(ctx->rgb8.as<uint8_t>() + f0 * N * 3, rgb + f0 * N * 3, cn * N * 3, hipMemcpyHostToDevice, ctx->in_stream));
+        FS_HIP(hipEventRecord(ctx->pipe_events[2 * k], ctx->in_stream));
+        return 0;
+    };
+    // the previous call's kernels may still read the input buffers when the caller drives the stream itself
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    if (upload(0)) return -1;
+    for (int k = 0; k < chunks; ++k) {
+        const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
+        if (k + 1 < chunks && upload(k + 1)) return -1;
+        FS_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[2 * k], 0));
+        if (fs_find_surfaces_batch_dev(ctx, (int)cn, ctx->depth16.as<uint16_t>() + f0 * N, ctx->rgb8.as<uint8_t>() + f0 * N * 3,
+                                       ctx->angles.as<float>() + f0 * N * 2, ctx->normals.as<float>() + f0 * N * 3,
+                                       ctx->points.as<float>() + f0 * N * 3, ctx->patches64.as<int64_t>() + f0 * N,
+                                       ctx->edges.as<int32_t>() + f0 * N, ctx->surfaces64.as<int64_t>() + f0 * N,
+                                       num_surfaces ? num_surfaces + f0 : nullptr))
+            return -1;
+        FS_HIP(hipEventRecord(ctx->pipe_events[2 * k + 1], ctx->stream));
+        FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->pipe_events[2 * k + 1], 0));
+        const size_t px = cn * N, o = f0 * N;
+        if (angles) FS_HIP(hipMemcpyAsync(angles + o * 2, ctx->angles.as<float>() + o * 2, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (surfaces) FS_HIP(hipMemcpyAsync(surfaces + o, ctx->surfaces64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+    }
+    FS_HIP(hipStreamSynchronize(ctx->out_stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+void *fs_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void fs_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *depth, const uint8_t *rgb, const float *angles,

@@ -311,7 +311,12 @@ def find_surfaces_for_indices(image_indices, mode="Gauss", kernel_size=standard_
             raise ValueError(f"images of one call must share a size, got {sorted(shapes)}")
         h, w = shapes.pop()
         ctx = _context(h, w, kernel_size, max_batch=min(frames_per_call, len(image_indices)), params=models[3].params)
-        res = ctx.find_surfaces_batch(np.stack([im[0] for im in images]), np.stack([im[1] for im in images]))
+        # frames are gathered in page-locked memory so that the uploads are DMA transfers
+        depth = _lib.pinned_empty((len(images), h, w), np.uint16)
+        rgb = _lib.pinned_empty((len(images), h, w, 3), np.uint8)
+        for j, im in enumerate(images):
+            depth[j], rgb[j] = im[0], im[1]
+        res = ctx.find_surfaces_batch(depth, rgb)
         for j, index in enumerate(chunk):
             print(index)
             data = {"depth": images[j][0], "rgb": images[j][1], "annotation": images[j][2]}
