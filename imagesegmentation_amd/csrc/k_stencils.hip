@@ -159,17 +159,37 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
     const int x = x0 + tx, y = y0 + ty;
     if (x >= W || y >= H) return;
     const float dc = td[ty + R][tx + R];
+    // Weight of a tap: m = |divide_no_nan(dj - dc, dc)| > 0.3 ? 0 : 1.  The rounded quotient differs
+    // from the exact one by less than one part in 1e7, so comparing |dj - dc| with 0.3 |dc| decides
+    // except in a band of that width around the threshold.  The window is summed with the product
+    // test; a pixel that met the band (about one tap in 1e6) is summed again with the division.
+    // dc == 0: divide_no_nan gives 0 and every weight is 1 (thresholds +inf).
+    const float lo = dc == 0.0f ? INFINITY : 0.3f * fabsf(dc) * (1.0f - 4e-7f);
+    const float hi = dc == 0.0f ? INFINITY : 0.3f * fabsf(dc) * (1.0f + 4e-7f);
     float sums = 0.0f, v0 = 0.0f, v1 = 0.0f;
+    bool band = false;
 #pragma unroll
     for (int wy = 0; wy <= 2 * R; ++wy)
 #pragma unroll
         for (int wx = 0; wx <= 2 * R; ++wx) {
-            float dj = td[ty + wy][tx + wx];
-            float m = fabsf(div_no_nan(dj - dc, dc)) > 0.3f ? 0.0f : 1.0f;
+            const float q = fabsf(td[ty + wy][tx + wx] - dc);
+            const float m = q > hi ? 0.0f : 1.0f;
+            band |= q >= lo && q <= hi;
             sums = sums + m;
             v0 = v0 + m * ta0[ty + wy][tx + wx];
             v1 = v1 + m * ta1[ty + wy][tx + wx];
         }
+    if (band) {
+        sums = 0.0f; v0 = 0.0f; v1 = 0.0f;
+        for (int wy = 0; wy <= 2 * R; ++wy)
+            for (int wx = 0; wx <= 2 * R; ++wx) {
+                const float dj = td[ty + wy][tx + wx];
+                const float m = fabsf(div_no_nan(dj - dc, dc)) > 0.3f ? 0.0f : 1.0f;
+                sums = sums + m;
+                v0 = v0 + m * ta0[ty + wy][tx + wx];
+                v1 = v1 + m * ta1[ty + wy][tx + wx];
+            }
+    }
     float2 o;
     o.x = div_no_nan(v0, sums);
     o.y = div_no_nan(v1, sums);
@@ -181,6 +201,43 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
 // ax[c] = |tanx[c-1] - tanx[c+1]|, ay[r] = |tany[r-1] - tany[r+1]| are
 // precomputed on the host with the same fp32 operations.
 // ---------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ float curvature_total(const float (&tile)[TH + 8][TW + 8 + 1], int ty, int tx, float dc, float dfx, float dfy)
+{
+    constexpr int R = 4;
+    float total = 0.0f;
+    const int d0s[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    const int d1s[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+            const float nx = dfx * (float)k, ny = dfy * (float)k;
+            const float nz = tile[ty + R - k * d0s[d]][tx + R - k * d1s[d]];
+            const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
+            const float a1 = (e0 * e0 + e1 * e1) + e2 * e2;
+            const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
+            const float a2 = (g0 * g0 + g1 * g1) + g2 * g2;
+            float dif1, dif2, score;
+            if (FAST) {
+                dif1 = __builtin_amdgcn_sqrtf(a1);
+                dif2 = __builtin_amdgcn_sqrtf(a2);
+                score = (dif2 == 0.0f ? 0.0f : (dif1 + prevd) * __builtin_amdgcn_rcpf(dif2)) - 1.0f;
+            } else {
+                dif1 = sqrtf(a1);
+                dif2 = sqrtf(a2);
+                score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
+            }
+            cur = cur + score;
+            total = total + cur;
+            prevd = dif2;
+            px = nx; py = ny; pz = nz;
+        }
+    }
+    return total;
+}
+
 __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restrict__ D, const float *__restrict__ ax,
                                                             const float *__restrict__ ay, float threshold,
                                                             uint8_t *__restrict__ mask, float *__restrict__ scores,
@@ -204,27 +261,19 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
     const float dc = tile[ty + R][tx + R];
     const float dfx = (ax[c] * dc) * 0.5f;
     const float dfy = (ay[r] * dc) * 0.5f;
-    float total = 0.0f;
-    const int d0s[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-    const int d1s[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
-#pragma unroll
-        for (int k = 1; k <= R; ++k) {
-            const float nx = dfx * (float)k, ny = dfy * (float)k;
-            const float nz = tile[ty + R - k * d0s[d]][tx + R - k * d1s[d]];
-            const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
-            const float dif1 = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
-            const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
-            const float dif2 = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
-            const float score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
-            cur = cur + score;
-            total = total + cur;
-            prevd = dif2;
-            px = nx; py = ny; pz = nz;
-        }
+    // Only the comparison with the threshold leaves this kernel (unless the caller asks for the
+    // scores), so the score is first evaluated with the hardware's approximate sqrt and reciprocal
+    // (1 ulp each).  Every term (dif1 + dif2_prev) / dif2 - 1 is >= 0 (triangle inequality), so
+    // near the threshold all ratios are <= 1 + threshold and the approximate total is within 4e-5
+    // of the correctly rounded one; outside a band of 2e-4 the comparison is decided, inside it
+    // the reference's correctly rounded evaluation is repeated (about one pixel in a thousand).
+    float total;
+    bool decided = false;
+    if (!scores) {
+        total = curvature_total<true>(tile, ty, tx, dc, dfx, dfy);
+        decided = fabsf(total - threshold) > 2e-4f;           // false for NaN: then the exact evaluation decides
     }
+    if (!decided) total = curvature_total<false>(tile, ty, tx, dc, dfx, dfy);
     if (scores) scores[i] = total;
     const uint8_t pix = total < threshold ? 1 : 0;
     mask[i] = dc > 0.001f ? pix : 0;
