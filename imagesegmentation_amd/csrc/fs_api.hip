@@ -355,7 +355,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
     if (fused) {
         ScopedTimer t(ctx, G_SIM);
-        launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->stream);
+        launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->params, ctx->stream);
     }
     for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
         const int gn = (n - g0) < G ? (n - g0) : G;

@@ -157,7 +157,7 @@ void launch_crf_lr_explicit(const float *unary, const float *Q, const float *f1,
 int crf_fused_tile_height(int r);        // 16 or 8 rows (tile width 32), 0 if the window is too large for the fused kernel
 void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
-                              size_t total, hipStream_t st);
+                              size_t total, const CrfParams &P, hipStream_t st);
 // CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
 // planes of a tile's listed labels and of its representative are written (see k_crf.hip).
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,

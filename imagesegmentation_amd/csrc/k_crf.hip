@@ -33,6 +33,8 @@
 // the neighbour p+o and plane[p-o] for the neighbour p-o.  The second read is the
 // first read of the lane that owns p-o at the same step, so within a tile both
 // uses of a similarity value reach L2/HBM once.
+#include <cmath>
+
 #include "fs_common.h"
 #ifndef FS_SKIPMAIN
 #define FS_SKIPMAIN 0
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // On the first update Q is synthesised from the patch labels
 // (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
 // ---------------------------------------------------------------------------
-struct FusedConsts { float K1, K2, K3, C2, C3, evidence; };
+struct FusedConsts { float K1, K2, K3, evidence; };
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
@@ -650,8 +652,8 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
                 const f2 t = (dj - cd) * inv;
                 const f2 u = t * t;
                 const f2 x1 = f2{K.K1, K.K1} * u;
-                const f2 x2 = __builtin_elementwise_fma(f2{K.C2, K.C2}, ec, f2{K.K2, K.K2} * u);
-                const f2 x3 = __builtin_elementwise_fma(f2{K.C3, K.C3}, ea, f2{K.K3, K.K3} * u);
+                const f2 x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);     // colours and angles are stored pre-scaled
+                const f2 x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
                 const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
                 const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
                 const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
@@ -833,15 +835,19 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     }
 }
 
-// depth u16 / rgb u8 / angles -> the float records the fused update stages: (d, r, g, b) and (a0, a1)
+// depth u16 / rgb u8 / angles -> the float records the fused update stages: (d, r, g, b) and (a0, a1).
+// Colours and angles carry the square root of their coefficient in the Gaussian exponents (cscale, ascale),
+// so that squared differences of the stored values are the exponent terms themselves; 1 for the linear similarity.
 __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ rgb,
                                                                 const float *__restrict__ angles, float4 *__restrict__ featA,
-                                                                float2 *__restrict__ featB, size_t total)
+                                                                float2 *__restrict__ featB, size_t total, float cscale,
+                                                                float ascale)
 {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
-    featA[q] = make_float4((float)depth[q], (float)rgb[3 * q], (float)rgb[3 * q + 1], (float)rgb[3 * q + 2]);
-    featB[q] = reinterpret_cast<const float2 *>(angles)[q];
+    featA[q] = make_float4((float)depth[q], cscale * (float)rgb[3 * q], cscale * (float)rgb[3 * q + 1], cscale * (float)rgb[3 * q + 2]);
+    const float2 a = reinterpret_cast<const float2 *>(angles)[q];
+    featB[q] = make_float2(ascale * a.x, ascale * a.y);
 }
 
 template <int R, int PY, int NCH>
@@ -958,11 +964,16 @@ void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)
     *tiles_y = th ? (H + th - 1) / th : 0;
 }
 
+// log2(e) * theta^2 * normaliser^2 of the colour and angle terms (find_surfaces.py:20, 343-349): colours / 50, angles * 2
+static double fused_c2(const CrfParams &P) { return P.t23 / 2500.0 * 1.4426950408889634; }
+static double fused_c3(const CrfParams &P) { return 4.0 * P.t33 * 1.4426950408889634; }
+
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
-                              size_t total, hipStream_t st)
+                              size_t total, const CrfParams &P, hipStream_t st)
 {
+    const float cs = P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f, as = P.mode == 0 ? (float)std::sqrt(fused_c3(P)) : 1.0f;
     hipLaunchKernelGGL(crf_pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, depth, rgb, angles,
-                       reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total);
+                       reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total, cs, as);
 }
 
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
@@ -974,7 +985,6 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     // delta_d = 12 t with t = (dq-dp)/(dp+dq); colour differences scaled by 1/50, angles by 2 (find_surfaces.py:20, 343-349)
     FusedConsts K;
     K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
-    K.C2 = (float)(P.t23 / 2500.0 * l2e); K.C3 = (float)(4.0 * P.t33 * l2e);
     K.evidence = P.evidence;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
     const int th = crf_fused_tile_height(g.r);
