@@ -621,23 +621,42 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
     const f2 cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
     (void)cinv;
-    // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i
-    for (int jr = 0; jr < 2 + 2 * r; ++jr) {
+    // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i.
+    // The operands of the next window position are read from LDS before the arithmetic of the current
+    // one starts (the scheduling barriers keep that order), so the read latency hides behind ~150 cycles
+    // of vector work of the same wave instead of stalling it.
+    struct Operands { float4 fa; float2 fb; float4 q0, q1; };
+    struct Row { const float4 *Q0, *Q1, *A; const float2 *B; };
+    auto row_of = [&](int jr) {
         const int rowbase = (trow + jr) * LW + col;       // window column dx = -r (LDS offsets are unsigned)
         // one opaque LDS index per plane, so that every read of the row is base register + immediate
         int iQ0 = rowbase, iQ1 = rowbase + plane4, iA = rowbase + 2 * plane4, iB = rowbase + 6 * plane4;
         asm volatile("" : "+v"(iQ0), "+v"(iQ1), "+v"(iA), "+v"(iB));
-        const float4 *rowQ0 = lds4 + iQ0, *rowQ1 = lds4 + iQ1, *rowA = lds4 + iA;
-        const float2 *rowB = reinterpret_cast<const float2 *>(lds4) + iB;
+        return Row{lds4 + iQ0, lds4 + iQ1, lds4 + iA, reinterpret_cast<const float2 *>(lds4) + iB};
+    };
+    auto read = [&](const Row &rw, int k) {
+        Operands o;
+        o.fa = rw.A[k];
+        o.fb = rw.B[k];
+        o.q0 = rw.Q0[k];
+        o.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NQ > 1) o.q1 = rw.Q1[k];
+        return o;
+    };
+    const int last_row = 1 + 2 * r;
+    Row cur = row_of(0);
+    Operands nxt = read(cur, 0);
+    for (int jr = 0; jr <= last_row; ++jr) {
+        const Row below = row_of(jr < last_row ? jr + 1 : last_row);
         const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : kw) * kw + r;          // weights of row 0's dy (zero row when out of reach)
         const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : kw) * kw + r;          // ... and of row 1's
 #pragma unroll
         for (int dx = -r; dx <= r; ++dx) {
-            const float4 fa = rowA[dx + r];
-            const float2 fb = rowB[dx + r];
-            const float4 q0 = rowQ0[dx + r];
-            float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NQ > 1) q1 = rowQ1[dx + r];
+            const Operands o = nxt;
+            nxt = dx < r ? read(cur, dx + r + 1) : read(below, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 fa = o.fa, q0 = o.q0, q1 = o.q1;
+            const float2 fb = o.fb;
             const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
             const f2 dj = f2{fa.x, fa.x};
             const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
@@ -685,7 +704,9 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
                     acc[i][7] = fmaf(sI, q1.w, acc[i][7]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        cur = below;
     }
 }
 
