@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // On the first update Q is synthesised from the patch labels
 // (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
 // ---------------------------------------------------------------------------
-struct FusedConsts { float K1, K2, K3, evidence; };
+struct FusedConsts { float K1, K2, K3, evidence; float uw[4]; };   // uw: the window's common (w1', w2', w3', bias) when uniform
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
@@ -604,7 +604,7 @@ constexpr int FTW = 32;                       // tile width of the fused kernel
 // the pair that a neighbour row does not reach, so no masking is left in the loop.
 // The relative depth difference divides by (d_p + d_q): a lane whose own depth is 0 may produce
 // NaN here; its result is overridden afterwards (Q[depth == 0]) and never read.
-template <int R, int NQ, int MODE>
+template <int R, int NQ, int MODE, bool UNIFORM>
 __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float4 *lds4, int plane4, int LW, int trow, int col, int r,
                                                  const FusedConsts &K, const float4 *__restrict__ wtab)
 {
@@ -650,6 +650,13 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         const Row below = row_of(jr < last_row ? jr + 1 : last_row);
         const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : kw) * kw + r;          // weights of row 0's dy (zero row when out of reach)
         const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : kw) * kw + r;          // ... and of row 1's
+        // UNIFORM: every offset of the window carries the same constants (the trained position thetas
+        // underflow to 0), so they live in four scalar registers, switched off per row where a neighbour
+        // row is out of a pixel's reach and at the centre; no table loads compete with the LDS reads
+        const float m0 = jr <= 2 * r ? 1.0f : 0.0f, m1 = jr >= 1 ? 1.0f : 0.0f;
+        const float4 u0 = make_float4(K.uw[0] * m0, K.uw[1] * m0, K.uw[2] * m0, K.uw[3] * m0);
+        const float4 u1 = make_float4(K.uw[0] * m1, K.uw[1] * m1, K.uw[2] * m1, K.uw[3] * m1);
+        const float c0 = jr == r ? 0.0f : 1.0f, c1 = jr == r + 1 ? 0.0f : 1.0f;
 #pragma unroll
         for (int dx = -r; dx <= r; ++dx) {
             const Operands o = nxt;
@@ -657,7 +664,16 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
             __builtin_amdgcn_sched_barrier(0);
             const float4 fa = o.fa, q0 = o.q0, q1 = o.q1;
             const float2 fb = o.fb;
-            const float4 w0 = wrow0[dx], w1 = wrow1[dx];                           // uniform (scalar loads)
+            float4 w0, w1;
+            if (UNIFORM) {
+                w0 = u0; w1 = u1;
+                if (dx == 0) {
+                    w0 = make_float4(u0.x * c0, u0.y * c0, u0.z * c0, u0.w * c0);
+                    w1 = make_float4(u1.x * c1, u1.y * c1, u1.z * c1, u1.w * c1);
+                }
+            } else {
+                w0 = wrow0[dx]; w1 = wrow1[dx];                                       // wave-uniform (scalar loads)
+            }
             const f2 dj = f2{fa.x, fa.x};
             const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
             const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
@@ -710,7 +726,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
 }
 
-template <int R, int TH, int NCH, int MODE>
+template <int R, int TH, int NCH, int MODE, bool UNIFORM>
 __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last)
 {
@@ -840,8 +856,8 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
             __syncthreads();
             if (wave_work && FS_SKIPMAIN == 0) {
                 // 1..4 channels of the chunk need only the first quad plane (two thirds of all tiles)
-                if (CE - ch * CH <= 4) fused_accumulate<R, 1, MODE>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
-                else fused_accumulate<R, 2, MODE>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                if (CE - ch * CH <= 4) fused_accumulate<R, 1, MODE, UNIFORM>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                else fused_accumulate<R, 2, MODE, UNIFORM>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
             }
         }
     }
@@ -888,12 +904,12 @@ hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &
     return hipGetLastError();
 }
 
-template <int R, int TH, int NCH, int MODE>
+template <int R, int TH, int NCH, int MODE, bool UNIFORM = false>
 hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
                           float weight, int first, int last, hipStream_t st)
 {
     static size_t attr_lds = 0;                  // dynamic LDS the kernel has been allowed so far
-    auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE>;
+    auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE, UNIFORM>;
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
     const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8);
     if (lds + lds_static > 160 * 1024) return hipErrorInvalidValue;
@@ -1007,8 +1023,21 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     FusedConsts K;
     K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
     K.evidence = P.evidence;
+    // the window's constants are uniform when the position terms vanish (as with the trained parameters)
+    const bool uniform = P.mode == 0 && P.t11 == 0.0f && P.t21 == 0.0f && P.t31 == 0.0f;
+    K.uw[0] = P.w1; K.uw[1] = P.w2; K.uw[2] = P.w3; K.uw[3] = P.bias;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
     const int th = crf_fused_tile_height(g.r);
+#define FS_FUSED_CASES_U(RR, THH)                                                                            \
+    switch (channel_class) {                                                                                 \
+    case 1: return launch_fused_t<RR, THH, 1, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
+    case 2: return launch_fused_t<RR, THH, 2, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
+    case 3:                                                                                                  \
+    case 4: return launch_fused_t<RR, THH, 4, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
+    case 8: return launch_fused_t<RR, THH, 8, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
+    case 16: return launch_fused_t<RR, THH, 16, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st); \
+    default: return hipErrorInvalidValue;                                                                    \
+    }
 #define FS_FUSED_CASES(RR, THH)                                                                              \
     switch (channel_class) {                                                                                 \
     case 1: return launch_fused_t<RR, THH, 1, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
@@ -1030,10 +1059,11 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
                                       : launch_fused_t<0, 8, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);
         return hipErrorInvalidValue;
     }
-    if (g.r == 7) { FS_FUSED_CASES(7, 16) }
+    if (g.r == 7 && uniform) { FS_FUSED_CASES_U(7, 16) }
     if (th == 16) { FS_FUSED_CASES(0, 16) }
     if (th == 8) { FS_FUSED_CASES(0, 8) }
 #undef FS_FUSED_CASES
+#undef FS_FUSED_CASES_U
     return hipErrorInvalidValue;
 }
 

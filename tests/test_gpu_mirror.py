@@ -166,3 +166,20 @@ def test_batch_and_shard_invariance():
     for i in range(len(idx)):
         assert set(np.unique(whole["surfaces"][i])) <= set(np.unique(whole["patches"][i])) | {0}
         assert (whole["surfaces"][i][d[i] == 0] == 0).all()        # invalid depth is never assigned
+
+
+def test_position_dependent_weights(oracle):
+    """Parameters whose position thetas do not vanish: the per-offset weight table is used instead of
+    the uniform-window constants."""
+    from imagesegmentation_amd._lib import Context
+    g = np.load(os.path.join(GOLD, "synth_11.npz"))
+    p = oracle.gauss_params().copy()
+    p[4:7] = [3.0, 5.0, 2.0]           # theta_1_1, theta_2_1, theta_3_1 (squared inside)
+    p[3] = 0.05                        # and a non-zero bias
+    with Context(96, 128, params=p) as ctx:
+        got = ctx.find_surfaces_batch(g["depth"], g["rgb"])
+    ref = oracle.find_surfaces(g["depth"], g["rgb"], p, want_q=True)
+    assert np.array_equal(got["patches"], ref["patches"])
+    assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
+    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.005
+    assert (ref["surfaces"] != g["surfaces"]).any()      # the parameters matter
