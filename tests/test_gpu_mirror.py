@@ -183,3 +183,28 @@ def test_position_dependent_weights(oracle):
     assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
     assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.005
     assert (ref["surfaces"] != g["surfaces"]).any()      # the parameters matter
+
+
+def test_degenerate_frames(oracle):
+    """Frames without any valid depth, without any patch, and with sides that are no multiple of the
+    tile sizes."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = 50, 70
+    d, c = make_batch([41, 42, 43], H, W)
+    d[0] = 0                                       # nothing valid: no patches, every label 0
+    d[1] = 1500                                    # a plane seen head-on: one patch
+    with Context(H, W, max_batch=3) as ctx:
+        got = ctx.find_surfaces_batch(d, c)
+    assert got["num_surfaces"][0] == 1 and not got["patches"][0].any() and not got["surfaces"][0].any()
+    for i in range(3):
+        ref = oracle.find_surfaces(d[i], c[i], oracle.gauss_params(), want_q=True)
+        assert got["num_surfaces"][i] == ref["num_surfaces"]
+        assert np.array_equal(got["patches"][i], ref["patches"])
+        assert np.array_equal(got["depth_edges"][i], ref["depth_edges"])
+        assert np.array_equal(got["points_3d"][i], ref["points_3d"])
+        assert _ties_only(got["surfaces"][i], ref["surfaces"], ref["q_final"])
+    assert got["num_surfaces"][1] == 2 and (got["surfaces"][1][10:-10, 10:-10] == 1).all()
+    with pytest.raises(RuntimeError):
+        with Context(H, W, max_batch=1) as ctx:
+            ctx.find_surfaces_batch(d[:2], c[:2])     # batch larger than max_batch
