@@ -43,6 +43,7 @@ SIGNATURES = {
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
     "fs_chi_squared_distances": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "fs_nearest_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_set_timing": (_i, [_vp, _i]),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
 }
@@ -350,6 +351,21 @@ class Context:
         out = np.empty((int(num_detections), int(num_annotations)))
         self._check(self._lib.fs_overlap_counts(self._h, _ptr(a), _ptr(o), int(num_annotations), int(num_detections), _ptr(out)))
         return out
+
+    def nearest_points(self, point_sets, target_points):
+        """calculate_nearest_points (process_surfaces.py:649-654): lists of [n_i, 2] point arrays and of
+        [m_i, 2] target arrays -> list of int32 [m_i, 2] arrays."""
+        if len(point_sets) != len(target_points):
+            raise ValueError("need as many target lists as point sets")
+        pts = [np.asarray(p, np.float32).reshape(-1, 2) for p in point_sets]
+        tgs = [np.asarray(t, np.float32).reshape(-1, 2) for t in target_points]
+        po = np.concatenate([[0], np.cumsum([len(p) for p in pts])]).astype(np.int32)
+        to = np.concatenate([[0], np.cumsum([len(t) for t in tgs])]).astype(np.int32)
+        P = _arr(np.concatenate(pts) if pts else np.zeros((0, 2)), np.float32)
+        T = _arr(np.concatenate(tgs) if tgs else np.zeros((0, 2)), np.float32)
+        out = np.empty((len(T), 2), np.int32)
+        self._check(self._lib.fs_nearest_points(self._h, len(pts), _ptr(P), _ptr(po), _ptr(T), _ptr(to), _ptr(out)))
+        return [out[to[i]:to[i + 1]] for i in range(len(tgs))]
 
     def apply_crf(self, labels, depth, rgb, angles):
         lab, single = self._batch(labels)

@@ -1002,4 +1002,39 @@ int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *det
     return 0;
 }
 
+int fs_nearest_points(fs_ctx *ctx, int groups, const float *points, const int32_t *point_offsets, const float *targets,
+                      const int32_t *target_offsets, int32_t *out)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (groups < 1 || !points || !point_offsets || !targets || !target_offsets || !out) return ctx->fail("fs_nearest_points: bad arguments");
+    const int P = point_offsets[groups], T = target_offsets[groups];
+    if (point_offsets[0] != 0 || target_offsets[0] != 0 || P < 0 || T < 0) return ctx->fail("fs_nearest_points: offsets must start at 0");
+    std::vector<int32_t> group_of(T);
+    for (int g = 0; g < groups; ++g) {
+        if (point_offsets[g + 1] < point_offsets[g] || target_offsets[g + 1] < target_offsets[g])
+            return ctx->fail("fs_nearest_points: offsets must not decrease");
+        if (target_offsets[g + 1] > target_offsets[g] && point_offsets[g + 1] == point_offsets[g])
+            return ctx->fail("fs_nearest_points: group " + std::to_string(g) + " has targets but no points");
+        for (int t = target_offsets[g]; t < target_offsets[g + 1]; ++t) group_of[t] = g;
+    }
+    if (T == 0) return 0;
+    auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t bp = up8((size_t)P * 8), bo = up8((size_t)(groups + 1) * 4), bt = up8((size_t)T * 8), bg = up8((size_t)T * 4);
+    FS_HIP(ctx->st_in.ensure(bp + bo + bt + bg));
+    FS_HIP(ctx->st_out.ensure((size_t)T * 8));
+    char *base = ctx->st_in.as<char>();
+    FS_HIP(hipMemcpyAsync(base, points, (size_t)P * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(base + bp, point_offsets, (size_t)(groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(base + bp + bo, targets, (size_t)T * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(base + bp + bo + bt, group_of.data(), (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_nearest_points(reinterpret_cast<const float *>(base), reinterpret_cast<const int32_t *>(base + bp),
+                          reinterpret_cast<const float *>(base + bp + bo), reinterpret_cast<const int32_t *>(base + bp + bo + bt), T,
+                          ctx->st_out.as<int32_t>(), ctx->stream);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipMemcpyAsync(out, ctx->st_out.p, (size_t)T * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 }  // extern "C"

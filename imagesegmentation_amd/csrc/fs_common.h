@@ -106,6 +106,9 @@ void launch_chi_squared(const double *hist, float *pooled, float *out, int A, in
 // overlap[nd][na] (zeroed by the caller) += 1 per pixel; *err = 1 if a label is out of range
 void launch_overlap_counts(const int64_t *annotation, const int64_t *detected, unsigned *overlap, int *err, int N, int nd, int na,
                            hipStream_t st);
+// nearest point of group target_group[t] to target t (device pointers); out [T][2], -1 for an empty group
+void launch_nearest_points(const float *points, const int32_t *point_offsets, const float *targets, const int32_t *target_group,
+                           int T, int32_t *out, hipStream_t st);
 // CRF (k_crf.hip)
 struct CrfFrameDesc {            // one frame of a batched launch (device-resident array of these)
     const float *sim0;           // similarity plane 0 of the frame (slack lies in front of it)

@@ -75,6 +75,43 @@ __global__ __launch_bounds__(256) void overlap_kernel(const int64_t *__restrict_
     }
 }
 
+// calculate_nearest_points_calc (process_surfaces.py:638-646): for every target of group g the point of
+// group g with the smallest squared distance (float32 arithmetic, first minimum).  One block per target.
+__global__ __launch_bounds__(256) void nearest_points_kernel(const float2 *__restrict__ points, const int32_t *__restrict__ point_offsets,
+                                                             const float2 *__restrict__ targets, const int32_t *__restrict__ target_group,
+                                                             int32_t *__restrict__ out)
+{
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    const int t = blockIdx.x, g = target_group[t];
+    const int a = point_offsets[g], b = point_offsets[g + 1];
+    const float2 tg = targets[t];
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = a + (int)threadIdx.x; k < b; k += 256) {      // ascending per thread: the first minimum stays
+        const float2 p = points[k];
+        const float dx = p.x - tg.x, dy = p.y - tg.y;
+        const float d = dx * dx + dy * dy;
+        if (d < best) { best = d; besti = k; }
+    }
+    sd[threadIdx.x] = best;
+    si[threadIdx.x] = besti;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float d2 = sd[threadIdx.x + off];
+            const int i2 = si[threadIdx.x + off];
+            if (d2 < sd[threadIdx.x] || (d2 == sd[threadIdx.x] && i2 < si[threadIdx.x])) { sd[threadIdx.x] = d2; si[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int k = si[0];
+        out[2 * t] = k == 0x7fffffff ? -1 : (int32_t)points[k].x;
+        out[2 * t + 1] = k == 0x7fffffff ? -1 : (int32_t)points[k].y;
+    }
+}
+
 }  // namespace
 
 void launch_chi_squared(const double *hist, float *pooled, float *out, int A, int B, int S, int ph, int pw, int sh, int sw,
@@ -93,6 +130,13 @@ void launch_overlap_counts(const int64_t *annotation, const int64_t *detected, u
     const int use_lds = (size_t)nd * na <= 8192;
     hipLaunchKernelGGL(overlap_kernel, dim3((N + 1023) / 1024), dim3(256), use_lds ? (size_t)nd * na * 4 : 0, st, annotation, detected,
                        overlap, err, N, nd, na, use_lds);
+}
+
+void launch_nearest_points(const float *points, const int32_t *point_offsets, const float *targets, const int32_t *target_group,
+                           int T, int32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(nearest_points_kernel, dim3(T), dim3(256), 0, st, reinterpret_cast<const float2 *>(points), point_offsets,
+                       reinterpret_cast<const float2 *>(targets), target_group, out);
 }
 
 }  // namespace fs

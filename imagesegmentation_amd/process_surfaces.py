@@ -59,6 +59,22 @@ def neighbor_lists(neighbor_counts):
     return [[j for j in range(1, S) if neighbor_counts[i][j] > 3] for i in range(S)]
 
 
+def calculate_nearest_points(point_sets, target_points):
+    """For every surface i and every target point of its list, the pixel of the surface's patch closest to
+    it (process_surfaces.py:638-654) -> list of int32 [m_i, 2] arrays."""
+    return _fs._context(_fs.height, _fs.width, _fs.standard_kernel_size).nearest_points(point_sets, target_points)
+
+
+def prepare_border_centers(neighbors, border_centers):
+    """Per surface the border centres towards its neighbours, (0, 0) if it has none
+    (process_surfaces.py:737-746)."""
+    result = []
+    for i in range(len(neighbors)):
+        rows = [border_centers[i][j] for j in neighbors[i]] or [np.asarray([0, 0])]
+        result.append(np.asarray(rows, dtype="float32"))
+    return result
+
+
 def extract_information_from_surface_data_and_preprocess_surfaces(data, texture_model):
     """Adds the per-surface statistics to `data` (process_surfaces.py:672-689): patch_points, surfaces
     (relabelled, disconnected parts removed), avg_pos, counts, centroids, texture, lab, hist_color,

@@ -174,6 +174,14 @@ int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int 
 int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *detected, int num_annotations,
                       int num_detections, double *overlap);
 
+/* calculate_nearest_points_calc (process_surfaces.py:638-646): `groups` point sets (points float32 [P][2],
+ * set g = rows point_offsets[g] .. point_offsets[g+1]) and as many target lists (targets float32 [T][2],
+ * target_offsets); out int32 [T][2] receives, for every target, the point of its own set with the smallest
+ * squared distance (float32 arithmetic, first minimum in list order), cast to int32 like the reference's
+ * result array. */
+int fs_nearest_points(fs_ctx *ctx, int groups, const float *points, const int32_t *point_offsets, const float *targets,
+                      const int32_t *target_offsets, int32_t *out);
+
 /* ---- instrumentation -------------------------------------------------------
  * group_mask bit g set: HIP events are recorded on the context's stream around
  * every launch of kernel group g; fs_get_timing() synchronises and returns the
