@@ -8,7 +8,7 @@ One step = one pass of the whole find_surfaces stage (depth smoothing, normals,
 angle filter, curvature mask, majority filters, depth edges, connected
 components, three mean-field CRF updates, argmax) over one batch of frames whose
 inputs are already resident in HBM.  The N=1 workload is the reference's OSD set
-(111 frames, 640x480: `main.find_surfaces_for_dataset`, BASELINE.json configs[1])
+(111 frames, 640x480: `main.find_surfaces_for_dataset` of the reference, main.py:25-26)
 when data/osd is present, otherwise seeded synthetic frames of the same shape.
 With N > 1 every rank processes its own batch of the same size (weak scaling, no
 data-path collective; frames are independent units).
@@ -180,9 +180,12 @@ def main():
             kk = (2 * args.kernel_size + 1) ** 2 - 1
             flops = float((N * kk * (45 + 2 * S)).sum()) * 3 * args.steps
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-            if os.path.exists(tpath) and args.workload == "osd" and args.kernel_size == 7:
-                with open(tpath) as f:
+            # HBM bytes per update from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+            # collected separately from this run: counters cannot share a run with the timing)
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if tfiles and args.workload == "osd" and args.kernel_size == 7:
+                with open(tfiles[-1]) as f:
                     traffic = json.load(f)["hbm_bytes_per_frame_update"]
             out["roofline"] = {"bound": "hbm", "kernel": "crf_iter_fused_kernel (mean-field update, similarity evaluated in the kernel)",
                                "per": "one mean-field update of one frame",

@@ -96,9 +96,12 @@ class _PinnedBlock:
         self.nbytes = int(nbytes)
 
     def __del__(self):
-        if getattr(self, "ptr", None):
-            self._lib.fs_host_free(self.ptr)
-            self.ptr = None
+        try:
+            if getattr(self, "ptr", None):
+                self._lib.fs_host_free(self.ptr)
+                self.ptr = None
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
 
 
 def pinned_empty(shape, dtype):
