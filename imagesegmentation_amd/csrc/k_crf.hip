@@ -751,42 +751,6 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     build_channel_list<256>(s_list, d.tile_recs, blockIdx.y * tiles_x + blockIdx.x, S);
     const int CE = s_list[0];
 
-    // ---- where to read each of my channels in the nine tiles the staged region touches ----
-    if (!first && tid < 15) {
-        const int sy = (int)blockIdx.y + tid / 3 - 2, sx = (int)blockIdx.x + tid % 3 - 1;
-        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
-        } else {
-            const int32_t *rec = d.tile_recs + ((size_t)sy * tiles_x + sx) * TILE_REC;
-            const int32_t *m = rec + REC_MASK;
-            int rep = 1;                                            // representative of the source tile
-            while (rep < S - 1 && ((unsigned)m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
-            for (int c = 0; c < CE; ++c) {
-                const int l = s_list[REC_LAB + c];
-                const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = listed ? l : rep;
-            }
-        }
-    }
-
-    // ---- features of tile + halo (zero outside the frame, like the reference's padded feature maps) ----
-    for (int ly = wv; ly < LH; ly += 4) {
-        const int gy = iy0 - r + ly;
-        const bool rowin = gy >= 0 && gy < Hi;
-        for (int lx = lane; lx < LW; lx += 64) {
-            const int gxx = ix0 - r + lx;
-            float4 fa = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 fb = make_float2(0.f, 0.f);
-            if (rowin && gxx >= 0 && gxx < Wi) {
-                const size_t q = (size_t)gy * Wi + gxx;
-                fa = d.featA[q];
-                fb = d.featB[q];
-            }
-            featA[ly * LW + lx] = fa;
-            featB[ly * LW + lx] = fb;
-        }
-    }
-
     // ---- per-lane pixel pair: column lane & 31, rows (wave, lane half) ----
     const int col = lane & 31, half = lane >> 5;
     // TH = 16: wave covers rows 4*wv .. 4*wv+3, half 0 -> rows 4wv, 4wv+1; half 1 -> 4wv+2, 4wv+3
@@ -807,6 +771,46 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     }
     const bool wave_work = __ballot(any_work) != 0ull;
 
+    // a tile without a single valid depth (about one in five on sensor data) only writes the override values:
+    // nothing is staged for it
+    const bool block_work = __syncthreads_or(any_work) != 0;
+
+    // ---- where to read each of my channels in the nine tiles the staged region touches ----
+    if (block_work && !first && tid < 15) {
+        const int sy = (int)blockIdx.y + tid / 3 - 2, sx = (int)blockIdx.x + tid % 3 - 1;
+        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
+            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
+        } else {
+            const int32_t *rec = d.tile_recs + ((size_t)sy * tiles_x + sx) * TILE_REC;
+            const int32_t *m = rec + REC_MASK;
+            int rep = 1;                                            // representative of the source tile
+            while (rep < S - 1 && ((unsigned)m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
+            for (int c = 0; c < CE; ++c) {
+                const int l = s_list[REC_LAB + c];
+                const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
+                s_src[tid][c] = listed ? l : rep;
+            }
+        }
+    }
+
+    // ---- features of tile + halo (zero outside the frame, like the reference's padded feature maps) ----
+    for (int ly = block_work ? wv : LH; ly < LH; ly += 4) {
+        const int gy = iy0 - r + ly;
+        const bool rowin = gy >= 0 && gy < Hi;
+        for (int lx = lane; lx < LW; lx += 64) {
+            const int gxx = ix0 - r + lx;
+            float4 fa = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 fb = make_float2(0.f, 0.f);
+            if (rowin && gxx >= 0 && gxx < Wi) {
+                const size_t q = (size_t)gy * Wi + gxx;
+                fa = d.featA[q];
+                fb = d.featB[q];
+            }
+            featA[ly * LW + lx] = fa;
+            featB[ly * LW + lx] = fb;
+        }
+    }
+
     float acc[NCH][2][CH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     __syncthreads();                                        // s_src, features
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        if (ch * CH < CE) {
+        if (block_work && ch * CH < CE) {
             if (ch > 0) __syncthreads();
             // ---- stage channels [ch*8, ch*8+8) of Q for tile + halo ----
             for (int ly = wv; ly < LH; ly += 4) {
