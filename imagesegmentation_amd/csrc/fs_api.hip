@@ -269,7 +269,8 @@ int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, int frames, float **plane0, s
     return 0;
 }
 
-constexpr int kCrfGroup = 16;   // frames whose similarity planes are resident at a time
+constexpr int kCrfGroup = 37;   // frames per batched CRF launch (Q planes of one group are resident at a time)
+constexpr int kPipeChunk = 16;  // frames per upload / compute / download step of the host-buffer entry point
 
 // CRF of n frames resident on the device: similarity planes, initial probabilities from
 // `labels32`, `iterations` mean-field updates, argmax.  S[i] label channels and max_active[i]
@@ -730,7 +731,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
     // Frames go through in chunks: the upload of chunk k+1 and the download of chunk k-1 run on their
     // own streams beside the kernels of chunk k.  With pinned host memory (fs_host_alloc) the copies are
     // true DMA transfers; with pageable memory the runtime stages them and the overlap is partial.
-    const int C = kCrfGroup;
+    const int C = kPipeChunk;
     const int chunks = (n + C - 1) / C;
     while (ctx->pipe_events.size() < (size_t)2 * chunks) {
         hipEvent_t e;

@@ -948,6 +948,7 @@ void crf_tile_grid(int H, int W, int *tiles_x, int *tiles_y)
 int crf_channel_class(int channels)
 {
     const int nch = (channels + 7) / 8;
+    if (nch <= 2) return 2;       // one launch for the bulk of the frames: the 16-channel variant is as fast on 8
     if (nch <= 4) return nch;
     if (nch <= 8) return 8;
     return 16;
