@@ -728,7 +728,8 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
 
 template <int R, int TH, int NCH, int MODE, bool UNIFORM>
 __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
-                                                             const float4 *__restrict__ wtab, float weight, int first, int last)
+                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
+                                                             int nframes)
 {
     constexpr int CH = 8;
     static_assert(TH == 16 || TH == 8, "tile height");
@@ -736,19 +737,29 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     __shared__ int s_list[TILE_REC];
     __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
 
-    const CrfFrameDesc d = descs[blockIdx.z];
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id; each XCD has its own L2.  The
+    // tiles are therefore numbered so that an XCD receives a contiguous run of them (whole frames, mostly):
+    // the halo a tile shares with its neighbours is then served by that XCD's L2 instead of being fetched
+    // once per XCD.
+    const int tiles_x = (g.Wi + FTW - 1) / FTW, tiles_y = (g.Hi + TH - 1) / TH;
+    const unsigned tiles_total = (unsigned)tiles_x * tiles_y * nframes;
+    const unsigned per_xcd = (tiles_total + 7u) / 8u;
+    const unsigned tile_id = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= tiles_total) return;
+    const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
+    const int by = brem / tiles_x, bx = brem - by * tiles_x;
+    const CrfFrameDesc d = descs[bz];
     const int r = R ? R : g.r, S = d.S;
     const int LW = FTW + 2 * r, LH = TH + 2 * r;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ix0 = blockIdx.x * FTW, iy0 = blockIdx.y * TH;            // fused path: output window = frame
+    const int ix0 = bx * FTW, iy0 = by * TH;                            // fused path: output window = frame
     const int Wi = g.Wi, Hi = g.Hi;
     const size_t Ni = (size_t)Hi * Wi;
     const int plane4 = LH * LW;
     float4 *featA = lds4 + 2 * plane4;
     float2 *featB = reinterpret_cast<float2 *>(featA + plane4);
-    const int tiles_x = gridDim.x, tiles_y = gridDim.y;
 
-    build_channel_list<256>(s_list, d.tile_recs, blockIdx.y * tiles_x + blockIdx.x, S);
+    build_channel_list<256>(s_list, d.tile_recs, by * tiles_x + bx, S);
     const int CE = s_list[0];
 
     // ---- per-lane pixel pair: column lane & 31, rows (wave, lane half) ----
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
 
     // ---- where to read each of my channels in the nine tiles the staged region touches ----
     if (block_work && !first && tid < 15) {
-        const int sy = (int)blockIdx.y + tid / 3 - 2, sx = (int)blockIdx.x + tid % 3 - 1;
+        const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
         if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
             for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
         } else {
@@ -830,7 +841,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
             for (int ly = wv; ly < LH; ly += 4) {
                 const int gy = iy0 - r + ly;
                 const bool rowin = gy >= 0 && gy < Hi;
-                const int sy = ((gy >> (TH == 16 ? 4 : 3)) - (int)blockIdx.y + 2) * 3;
+                const int sy = ((gy >> (TH == 16 ? 4 : 3)) - by + 2) * 3;
                 for (int lx = lane; lx < LW; lx += 64) {
                     const int gxx = ix0 - r + lx;
                     const bool in = rowin && gxx >= 0 && gxx < Wi;
@@ -846,7 +857,7 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
                             v[k] = x;
                         }
                     } else {
-                        const int st = sy + ((gxx >> 5) - (int)blockIdx.x + 1);
+                        const int st = sy + ((gxx >> 5) - bx + 1);
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
                             const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
@@ -922,8 +933,9 @@ hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom 
         if (e != hipSuccess) return e;
         attr_lds = lds;
     }
-    dim3 grid((g.Wi + FTW - 1) / FTW, (g.Hi + TH - 1) / TH, nframes);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last);
+    const unsigned tiles = (unsigned)((g.Wi + FTW - 1) / FTW) * ((g.Hi + TH - 1) / TH) * nframes;
+    dim3 grid((tiles + 7u) / 8u * 8u);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last, nframes);
     return hipGetLastError();
 }
 
