@@ -119,6 +119,54 @@ def test_numpy_crf_update_matches_c_oracle(oracle):
     assert np.abs(Q - whole).max() <= 2e-6
 
 
+def test_crf_update_against_float64_formula(oracle):
+    """Third, independent formulation: the update written from its formulas in float64 (no TF op
+    order, no float32 rounding) bounds the float32 oracle: potentials within 1e-4 relative."""
+    from numpy.lib.stride_tricks import sliding_window_view
+    g = gold("synth_13")
+    y0, x0, h, w, r = 30, 40, 24, 32, 7
+    sl = (slice(y0 - r, y0 + h + r), slice(x0 - r, x0 + w + r))
+    depth = g["depth"][sl].astype(np.float64)
+    rgb = g["rgb"][sl].astype(np.float64)
+    ang = g["angles"][sl].astype(np.float64)
+    ns = int(g["num_surfaces"])
+    S = ns + 1
+    unary32, q032, _ = oracle.unary_q0(g["patches"].astype(np.int64), ns)
+    Q = q032[sl].astype(np.float64)
+    unary = unary32[y0:y0 + h, x0:x0 + w].astype(np.float64)
+    p = oracle.gauss_params().astype(np.float64)
+    w1, w2, w3, bias = p[:4]
+    t11, t21, t31, t12, t22, t32, t23, t33 = p[4:12] ** 2
+    k = 2 * r + 1
+    win = lambda a: sliding_window_view(a, (k, k), (0, 1))            # [h, w, (C,) k, k]
+    dy, dx = np.meshgrid(np.arange(-r, r + 1), np.arange(-r, r + 1), indexing="ij")
+    pos = (dy / 40.0) ** 2 + (dx / 40.0) ** 2
+    dw = win(depth)
+    dc = depth[r:-r, r:-r][..., None, None]
+    den = (dc + dw) / 2
+    dd = np.where(den == 0, 0.0, (dw - dc) / np.where(den == 0, 1, den)) * 6
+    col = sum(((win(rgb[..., c]) - rgb[r:-r, r:-r, c][..., None, None]) / 50.0) ** 2 for c in range(3))
+    an = sum(((win(ang[..., c]) - ang[r:-r, r:-r, c][..., None, None]) * 2.0) ** 2 for c in range(2))
+    sim = (w1 * np.exp(-(t11 * pos + t12 * dd ** 2)) + w2 * np.exp(-(t21 * pos + t22 * dd ** 2 + t23 * col)) +
+           w3 * np.exp(-(t31 * pos + t32 * dd ** 2 + t33 * an)) + bias)
+    sim[:, :, r, r] = 0
+    msg = np.einsum("hwyx,hwlyx->hwl", sim, win(Q))
+    msg[..., -1] += 0.00005
+    pot = unary + p[12] * (msg.sum(-1, keepdims=True) - msg)
+    # the float32 oracle on the same window
+    grid = np.stack(np.meshgrid(np.arange(h + 2 * r), np.arange(w + 2 * r), indexing="ij"), -1).astype(np.float32)
+    f1 = np.concatenate([grid, depth[..., None]], -1)[None]
+    f2 = np.concatenate([f1[0], rgb], -1)[None]
+    f3 = np.concatenate([f1[0], ang], -1)[None]
+    val = np.zeros(S, np.float32)
+    val[-1] = 1
+    out32, pot32 = oracle.crf_step(unary[None], Q[None], f1, f2, f3, val, oracle.gauss_params(), r, want_potentials=True)
+    assert np.abs(pot32[0] - pot).max() <= 1e-4 * np.abs(pot).max()
+    q64 = np.exp(-(pot - pot.min(-1, keepdims=True)))
+    q64 /= q64.sum(-1, keepdims=True)
+    assert np.abs(out32[0] - q64).max() <= 2e-5
+
+
 def test_numpy_lr_update_matches_c_oracle(oracle):
     """conv_crf_LR: numpy windows vs C loops, shipped parameters and a softer set."""
     from oracle import oracle_np as N
