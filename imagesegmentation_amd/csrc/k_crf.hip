@@ -3,12 +3,18 @@
 // host glue around it (get_inputs / assemble_outputs / the per-pixel unary loop,
 // find_surfaces.py:437-495) and the argmax + fix-ups of find_surfaces.py:520-532.
 //
+// Two update kernels share the pieces below:
+//   crf_iter_fused_kernel   the production path (fs_find_surfaces_batch, fs_apply_crf): features of the
+//                           frame, similarity evaluated in the kernel; described at its definition.
+//   crf_iter_kernel         the operator-level entry (fs_crf_step: conv_crf_Gauss.predict on arbitrary
+//                           feature tensors): similarity precomputed into planes simH.
+//
 // Data layout
 //   Q          label planes Q[l][pixel] (the reference is pixel-major): a lane per
 //              pixel then reads and writes 256 contiguous bytes per wave for every
 //              label it touches.
-//   simH       sim(p, q) = w1 s1 + w2 s2 + w3 s3 + bias is symmetric in (p, q) and
-//              identical in all mean-field iterations, so it is evaluated once per
+//   simH       (crf_iter_kernel only) sim(p, q) = w1 s1 + w2 s2 + w3 s3 + bias is symmetric in
+//              (p, q) and identical in all mean-field iterations, so it is evaluated once per
 //              frame for the "forward" half of the window (dy > 0, or dy == 0 and
 //              dx > 0) and kept as planes simH[offset][pixel]; the backward half is
 //              the neighbour's forward entry.  The buffer carries r*W + r zeroed
@@ -578,13 +584,15 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // Streaming precomputed similarities costs ~250 MB of HBM reads per frame and update, which
 // is what bounds the plane-based kernel; the six feature values of tile + halo fit in LDS next
 // to Q, so here every lane evaluates sim(p, q) itself:
-//   sim = w1'[o] 2^-(K1 u) + w2'[o] 2^-(K2 u + C2 |dc|^2) + w3'[o] 2^-(K3 u + C3 |da|^2) + bias
+//   sim = w1'[o] 2^-(K1 u) + w2'[o] 2^-(K2 u + |dc'|^2) + w3'[o] 2^-(K3 u + |da'|^2) + bias
+//   (c', a': colours and angles as stored by crf_pack_features, scaled by the root of their coefficient)
 //   u = ((dq - dp) / (dp + dq))^2  (0 when both depths are 0),
 // the reference's three Gaussian kernels (find_surfaces.py:343-355) with the normalisers and
 // squared thetas folded into K*, C* and log2(e), and the offset-dependent position terms folded
 // into per-offset weights w'[o] = w exp(-position term).
 //
-// Tile 32 x TH pixels, 4 waves; a lane owns two vertically adjacent pixels and keeps them as
+// Tile 32 x TH pixels, 4 waves (tiles are numbered so that each XCD works on a contiguous run of
+// them); a lane owns two vertically adjacent pixels and keeps them as
 // packed pairs, so the arithmetic is v_pk_*_f32 and one LDS read of a neighbour's features and
 // channel vector serves both pixels (the window is walked by neighbour row).
 //
