@@ -33,6 +33,22 @@ __device__ __forceinline__ float dec_f32(unsigned u)
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// hist[idx] += 1 for every active lane, one atomic per distinct idx of the wave: the pixels of a
+// planar, evenly coloured surface fall into very few bins, and thousands of atomics on one address
+// would serialise in L2.  Every lane of the wave must call this (inactive ones with active = false).
+__device__ __forceinline__ void wave_histogram_add(uint32_t *__restrict__ hist, uint32_t idx, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t key = __shfl(idx, leader);
+        const unsigned long long same = __ballot(active && idx == key) & todo;
+        if (lane == leader) atomicAdd(hist + key, (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // relabel, int32 working copies, interior counts and position sums, patch-pixel counts, sort input
 __global__ __launch_bounds__(SB) void stats_prepare_kernel(const int64_t *__restrict__ surfaces, const int64_t *__restrict__ patches,
                                                            int32_t *__restrict__ surf32, int32_t *__restrict__ pat32,
@@ -179,35 +195,43 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__r
                                                               float *__restrict__ norm, uint32_t *__restrict__ extent, int *__restrict__ err,
                                                               int H, int W, int S)
 {
-    extern __shared__ uint32_t she[];            // [S][8] encoded min/max of (norm, x, y, z) | [S] surface count | [S] patch count
+    // per-block copies of everything indexed by label: global atomics on one address per label would
+    // serialise (a patch has ~1e5 pixels), LDS atomics do not
+    extern __shared__ double shd[];              // [S][2] angle sums | then uint32: [S][8] min/max of (norm, x, y, z) | [S] surface count | [S] patch count
+    double *s_ang = shd;
+    uint32_t *she = reinterpret_cast<uint32_t *>(shd + 2 * S);
     uint32_t *s_cnt = she + 8 * S, *p_cnt = s_cnt + S;
     const int N = H * W;
     for (int i = threadIdx.x; i < 8 * S; i += SB) she[i] = (i & 1) ? 0u : ~0u;
-    for (int i = threadIdx.x; i < 2 * S; i += SB) s_cnt[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * S; i += SB) { s_cnt[i] = 0u; s_ang[i] = 0.0; }
     __syncthreads();
     for (int k = 0; k < SPB / SB; ++k) {
         const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
-        if (p >= N) continue;
-        const int y = p / W, x = p - y * W;
-        const int s = surf32[p];
-        // depth extent (every label, 0 included), :332-346
-        const float px = points_3d[3 * (size_t)p], py = points_3d[3 * (size_t)p + 1], pz = points_3d[3 * (size_t)p + 2];
-        const float n = sqrtf((px * px + py * py) + pz * pz);
-        norm[p] = n;
-        if (n != 0.0f) {
-            const float v[4] = {n, px, py, pz};
+        const bool in = p < N;
+        const int y = in ? p / W : 0, x = in ? p - y * W : 0;
+        const int s = in ? surf32[p] : 0;
+        uint32_t color_bin = 0, angle_bin = 0;
+        bool color_on = false, angle_on = false;
+        if (in) {
+            // depth extent (every label, 0 included), :332-346
+            const float px = points_3d[3 * (size_t)p], py = points_3d[3 * (size_t)p + 1], pz = points_3d[3 * (size_t)p + 2];
+            const float n = sqrtf((px * px + py * py) + pz * pz);
+            norm[p] = n;
+            if (n != 0.0f) {
+                const float v[4] = {n, px, py, pz};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned e = enc_f32(v[c]);
-                if (e < she[s * 8 + 2 * c]) atomicMin(&she[s * 8 + 2 * c], e);
-                if (e > she[s * 8 + 2 * c + 1]) atomicMax(&she[s * 8 + 2 * c + 1], e);
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned e = enc_f32(v[c]);
+                    if (e < she[s * 8 + 2 * c]) atomicMin(&she[s * 8 + 2 * c], e);
+                    if (e > she[s * 8 + 2 * c + 1]) atomicMax(&she[s * 8 + 2 * c + 1], e);
+                }
             }
         }
         if (s > 0) {
             // colour histogram, :265-267
             const long a = (long)rint(lab[3 * (size_t)p + 1] + 127.0), b = (long)rint(lab[3 * (size_t)p + 2] + 127.0);
             if (a < 0 || a > 255 || b < 0 || b > 255) *err = 2;
-            else atomicAdd(hist_color + ((size_t)a * 256 + b) * S + s, 1u);
+            else { color_on = true; color_bin = (uint32_t)((a * 256 + b) * S + s); }
             atomicAdd(&s_cnt[s], 1u);
             // neighbours, :39-55 (pairs with label 0 and pairs of equal labels are zeroed afterwards: skipped)
             if (edges[p] != 0) {
@@ -234,12 +258,14 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__r
                 const float a0 = angles[2 * (size_t)p], a1 = angles[2 * (size_t)p + 1];
                 const int i0 = (int)(((double)a0 / (2 * M_PI) + 0.5) * 39), i1 = (int)(((double)a1 / (2 * M_PI) + 0.5) * 39);
                 if (i0 < 0 || i0 > 39 || i1 < 0 || i1 > 39) *err = 3;
-                else atomicAdd(hist_angle + ((size_t)i0 * 40 + i1) * S + pl, 1u);
-                atomicAdd(angle_sum + 2 * pl, (double)a0);
-                atomicAdd(angle_sum + 2 * pl + 1, (double)a1);
+                else { angle_on = true; angle_bin = (uint32_t)((i0 * 40 + i1) * S + pl); }
+                atomicAdd(&s_ang[2 * pl], (double)a0);
+                atomicAdd(&s_ang[2 * pl + 1], (double)a1);
                 atomicAdd(&p_cnt[pl], 1u);
             }
         }
+        wave_histogram_add(hist_color, color_bin, color_on);
+        wave_histogram_add(hist_angle, angle_bin, angle_on);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 8 * S; i += SB) {
@@ -247,8 +273,10 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__r
         if (i & 1) { if (v != 0u) atomicMax(extent + i, v); }
         else if (v != ~0u) atomicMin(extent + i, v);
     }
-    for (int i = threadIdx.x; i < 2 * S; i += SB)
+    for (int i = threadIdx.x; i < 2 * S; i += SB) {
         if (s_cnt[i]) atomicAdd(cnt + i, s_cnt[i]);
+        if (s_ang[i] != 0.0) atomicAdd(angle_sum + i, s_ang[i]);
+    }
 }
 
 // texture vectors of every 4th pixel of a patch, :278-283: one block per texture row, a thread per component
@@ -389,7 +417,7 @@ hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const Sta
                        out.centroid_idx, cpix, W, S);
     launch_label_components(w.surf32, w.parent, w.count, 1, H, W, st);
     hipLaunchKernelGGL(stats_keep_kernel, dim3((N + SB - 1) / SB), dim3(SB), 0, st, w.surf32, w.parent, cpix, out.surfaces, N);
-    hipLaunchKernelGGL(stats_accumulate_kernel, dim3(nblk), dim3(SB), 10 * S * sizeof(uint32_t), st, w.surf32, w.pat32, in.depth_edges,
+    hipLaunchKernelGGL(stats_accumulate_kernel, dim3(nblk), dim3(SB), 10 * S * sizeof(uint32_t) + 2 * S * sizeof(double), st, w.surf32, w.pat32, in.depth_edges,
                        in.lab, in.angles, in.points_3d, hist_color, hist_angle, angle_sum, cnt, nb_count, nb_sum, out.norm, extent, err,
                        H, W, S);
     if (in.texture)
