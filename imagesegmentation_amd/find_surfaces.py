@@ -296,40 +296,59 @@ def find_surfaces(models, image_data, mode, kernel_size, plot_result=False, save
     return data
 
 
+io_workers = min(16, os.cpu_count() or 1)                 # threads decoding PNGs / writing .npy files
+timings = {"decode": 0.0, "gpu": 0.0, "save": 0.0, "images": 0}   # seconds spent by find_surfaces_for_indices, by phase
+
+
 def find_surfaces_for_indices(image_indices, mode="Gauss", kernel_size=standard_kernel_size, save_data=True, plot_result=False,
                               return_results=False):
     """find_surfaces for the images of the data set with the given indices
-    (find_surfaces.py:551-561).  Frames go to the GPU frames_per_call at a time."""
+    (find_surfaces.py:551-561).  Frames go to the GPU frames_per_call at a time; PNG decoding and the
+    .npy writes run on a thread pool (both release the GIL) and are accounted for in `timings`."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
     models = get_GPU_models(mode, kernel_size)
     image_indices = list(image_indices)
     results = []
-    for lo in range(0, len(image_indices), frames_per_call):
-        chunk = image_indices[lo:lo + frames_per_call]
-        images = [load_image(i) for i in chunk]
-        shapes = {im[0].shape for im in images}
-        if len(shapes) != 1:
-            raise ValueError(f"images of one call must share a size, got {sorted(shapes)}")
-        h, w = shapes.pop()
-        ctx = _context(h, w, kernel_size, max_batch=min(frames_per_call, len(image_indices)), params=models[3].params)
-        # frames are gathered in page-locked memory so that the uploads are DMA transfers
-        depth = _lib.pinned_empty((len(images), h, w), np.uint16)
-        rgb = _lib.pinned_empty((len(images), h, w, 3), np.uint8)
-        for j, im in enumerate(images):
-            depth[j], rgb[j] = im[0], im[1]
-        res = ctx.find_surfaces_batch(depth, rgb)
-        for j, index in enumerate(chunk):
-            print(index)
-            data = {"depth": images[j][0], "rgb": images[j][1], "annotation": images[j][2]}
-            for k in ("angles", "vectors", "points_3d", "patches", "depth_edges", "surfaces"):
-                data[k] = res[k][j]
-            data["num_surfaces"] = int(res["num_surfaces"][j])
-            if plot_result:
-                from .plot_image import plot_surfaces
-                plot_surfaces(data["surfaces"])
-            if save_data:
-                _li.save_surface_information(index, data)
-            if return_results:
-                results.append(data)
+    with ThreadPoolExecutor(max_workers=io_workers) as pool:
+        pending_saves = []
+        for lo in range(0, len(image_indices), frames_per_call):
+            chunk = image_indices[lo:lo + frames_per_call]
+            t0 = time.perf_counter()
+            images = list(pool.map(load_image, chunk))
+            shapes = {im[0].shape for im in images}
+            if len(shapes) != 1:
+                raise ValueError(f"images of one call must share a size, got {sorted(shapes)}")
+            h, w = shapes.pop()
+            ctx = _context(h, w, kernel_size, max_batch=min(frames_per_call, len(image_indices)), params=models[3].params)
+            # frames are gathered in page-locked memory so that the uploads are DMA transfers
+            depth = _lib.pinned_empty((len(images), h, w), np.uint16)
+            rgb = _lib.pinned_empty((len(images), h, w, 3), np.uint8)
+            for j, im in enumerate(images):
+                depth[j], rgb[j] = im[0], im[1]
+            t1 = time.perf_counter()
+            res = ctx.find_surfaces_batch(depth, rgb)
+            t2 = time.perf_counter()
+            for j, index in enumerate(chunk):
+                print(index)
+                data = {"depth": images[j][0], "rgb": images[j][1], "annotation": images[j][2]}
+                for k in ("angles", "vectors", "points_3d", "patches", "depth_edges", "surfaces"):
+                    data[k] = res[k][j]
+                data["num_surfaces"] = int(res["num_surfaces"][j])
+                if plot_result:
+                    from .plot_image import plot_surfaces
+                    plot_surfaces(data["surfaces"])
+                if save_data:
+                    pending_saves.append(pool.submit(_li.save_surface_information, index, data))
+                if return_results:
+                    results.append(data)
+            timings["decode"] += t1 - t0
+            timings["gpu"] += t2 - t1
+            timings["images"] += len(chunk)
+        t3 = time.perf_counter()
+        for f in pending_saves:
+            f.result()                          # re-raises a failed write
+        timings["save"] += time.perf_counter() - t3
     if return_results:
         return results
 

@@ -50,7 +50,7 @@ def find_surfaces_for_indices_sharded(image_indices, mode="Gauss", kernel_size=7
 
     def process(indices):
         fs.find_surfaces_for_indices(indices, mode=mode, kernel_size=kernel_size, save_data=save_data)
-        return {"images": len(indices)}
+        return {"images": len(indices), "decode_s": fs.timings["decode"], "gpu_s": fs.timings["gpu"], "save_wait_s": fs.timings["save"]}
     return run_sharded(image_indices, process)
 
 
@@ -75,6 +75,9 @@ def main(argv=None):
         n = sum(r["images"] for r in res)
         t = max(r["seconds"] for r in res)
         print(f"{n} images on {len(res)} GPU(s) in {t:.2f} s = {n / t:.1f} images/s (decode and .npy writes included)")
+        for r in res:
+            print(f"  rank {r['rank']}: {r['images']} images, PNG decode {r['decode_s']:.2f} s, upload + kernels + download "
+                  f"{r['gpu_s']:.2f} s, waiting for .npy writes {r['save_wait_s']:.2f} s")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
