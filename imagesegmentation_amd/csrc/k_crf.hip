@@ -813,20 +813,33 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     }
 
     // ---- features of tile + halo (zero outside the frame, like the reference's padded feature maps) ----
-    for (int ly = block_work ? wv : LH; ly < LH; ly += 4) {
-        const int gy = iy0 - r + ly;
-        const bool rowin = gy >= 0 && gy < Hi;
-        for (int lx = lane; lx < LW; lx += 64) {
-            const int gxx = ix0 - r + lx;
-            float4 fa = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 fb = make_float2(0.f, 0.f);
-            if (rowin && gxx >= 0 && gxx < Wi) {
+    // flat index over the staged region, three pixels per thread and pass: all global loads of a pass are
+    // issued before the first LDS store waits for one of them
+    const int staged = LH * LW;
+    constexpr int FU = 3;
+    for (int i0 = block_work ? tid : staged; i0 < staged; i0 += 256 * FU) {
+        float4 fa[FU];
+        float2 fb[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int i = i0 + u * 256;
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = iy0 - r + ly, gxx = ix0 - r + lx;
+            fa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            fb[u] = make_float2(0.f, 0.f);
+            if (i < staged && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi) {
                 const size_t q = (size_t)gy * Wi + gxx;
-                fa = d.featA[q];
-                fb = d.featB[q];
+                fa[u] = d.featA[q];
+                fb[u] = d.featB[q];
             }
-            featA[ly * LW + lx] = fa;
-            featB[ly * LW + lx] = fb;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int i = i0 + u * 256;
+            if (i < staged) {
+                featA[i] = fa[u];
+                featB[i] = fb[u];
+            }
         }
     }
 
@@ -845,16 +858,17 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
     for (int ch = 0; ch < NCH; ++ch) {
         if (block_work && ch * CH < CE) {
             if (ch > 0) __syncthreads();
-            // ---- stage channels [ch*8, ch*8+8) of Q for tile + halo ----
-            for (int ly = wv; ly < LH; ly += 4) {
-                const int gy = iy0 - r + ly;
-                const bool rowin = gy >= 0 && gy < Hi;
-                const int sy = ((gy >> (TH == 16 ? 4 : 3)) - by + 2) * 3;
-                for (int lx = lane; lx < LW; lx += 64) {
-                    const int gxx = ix0 - r + lx;
-                    const bool in = rowin && gxx >= 0 && gxx < Wi;
+            // ---- stage channels [ch*8, ch*8+8) of Q for tile + halo (same flat, batched scheme) ----
+            constexpr int QU = 2;
+            for (int i0 = tid; i0 < staged; i0 += 256 * QU) {
+                float v[QU][CH];
+#pragma unroll
+                for (int u = 0; u < QU; ++u) {
+                    const int i = i0 + u * 256;
+                    const int ly = i / LW, lx = i - ly * LW;
+                    const int gy = iy0 - r + ly, gxx = ix0 - r + lx;
+                    const bool in = i < staged && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
                     const size_t q = in ? (size_t)gy * Wi + gxx : 0;
-                    float v[CH];
                     if (first) {
                         const int lab = in ? d.patches[q] : -1;
 #pragma unroll
@@ -862,18 +876,24 @@ __global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc 
                             const int l = ch * CH + k < CE ? s_list[REC_LAB + ch * CH + k] : -1;
                             float x = 0.0f;
                             if (lab >= 0 && l > 0) x = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
-                            v[k] = x;
+                            v[u][k] = x;
                         }
                     } else {
-                        const int st = sy + ((gxx >> 5) - bx + 1);
+                        const int st = in ? ((gy >> (TH == 16 ? 4 : 3)) - by + 2) * 3 + ((gxx >> 5) - bx + 1) : 0;
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
                             const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
-                            v[k] = l >= 0 ? d.Qin[(size_t)l * Ni + q] : 0.0f;
+                            v[u][k] = l >= 0 ? d.Qin[(size_t)l * Ni + q] : 0.0f;
                         }
                     }
-                    lds4[ly * LW + lx] = make_float4(v[0], v[1], v[2], v[3]);
-                    if (CE - ch * CH > 4) lds4[plane4 + ly * LW + lx] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+#pragma unroll
+                for (int u = 0; u < QU; ++u) {
+                    const int i = i0 + u * 256;
+                    if (i < staged) {
+                        lds4[i] = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+                        if (CE - ch * CH > 4) lds4[plane4 + i] = make_float4(v[u][4], v[u][5], v[u][6], v[u][7]);
+                    }
                 }
             }
             __syncthreads();
