@@ -11,7 +11,7 @@
 using namespace fs;
 
 namespace {
-std::string g_create_error;
+thread_local std::string g_create_error;   // fs_create has no context to hold its message yet
 
 enum { G_STENCIL = 0, G_CC = 1, G_SIM = 2, G_INIT = 3, G_ITER = 4, G_COUNT = 5 };
 
@@ -530,6 +530,7 @@ int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches)
 int fs_smooth_depth(fs_ctx *ctx, int n, const float *depth, float *out)
 {
     if (check_batch(ctx, n)) return -1;
+    if (!depth || !out) return ctx->fail("fs_smooth_depth: null argument");
     const size_t bytes = (size_t)n * ctx->N() * 4;
     FS_HIP(ctx->depthf.ensure(bytes));
     FS_HIP(hipMemcpyAsync(ctx->depthf.p, depth, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -543,6 +544,7 @@ int fs_smooth_depth(fs_ctx *ctx, int n, const float *depth, float *out)
 int fs_normals(fs_ctx *ctx, int n, const float *smoothed, float *angles, float *vectors, float *points, float *raw_angles)
 {
     if (check_batch(ctx, n)) return -1;
+    if (!smoothed) return ctx->fail("fs_normals: null argument");
     const size_t px = (size_t)n * ctx->N();
     FS_HIP(hipMemcpyAsync(ctx->smoothed.p, smoothed, px * 4, hipMemcpyHostToDevice, ctx->stream));
     launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), ctx->points.as<float>(),
@@ -561,6 +563,7 @@ int fs_patches(fs_ctx *ctx, int n, const float *smoothed, int64_t *patches, int3
                uint8_t *curvature_mask)
 {
     if (check_batch(ctx, n)) return -1;
+    if (!smoothed) return ctx->fail("fs_patches: null argument");
     const size_t px = (size_t)n * ctx->N();
     FS_HIP(hipMemcpyAsync(ctx->smoothed.p, smoothed, px * 4, hipMemcpyHostToDevice, ctx->stream));
     if (curvature_scores) FS_HIP(ctx->scores.ensure(px * 4));
@@ -578,6 +581,7 @@ int fs_patches(fs_ctx *ctx, int n, const float *smoothed, int64_t *patches, int3
 int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_size_exclusive, int64_t *labels, int32_t *num_labels)
 {
     if (check_batch(ctx, n)) return -1;
+    if (!mask) return ctx->fail("fs_connected_components: null argument");
     const size_t px = (size_t)n * ctx->N();
     FS_HIP(hipMemcpyAsync(ctx->mask.p, mask, px, hipMemcpyHostToDevice, ctx->stream));
     launch_connected_components(ctx->mask.as<uint8_t>(), cc_work(ctx), min_size_exclusive, ctx->patches64.as<int64_t>(), nullptr, n, ctx->H, ctx->W, ctx->stream);
@@ -596,6 +600,7 @@ int fs_crf_step(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, con
     if (!ctx->have_params || ctx->params.mode != 0) return ctx->fail("fs_crf_step: call fs_set_gauss_params first");
     if (B < 1 || h < 1 || w < 1 || S < 2) return ctx->fail("fs_crf_step: bad shape");
     if (S > kMaxTileChannels) return ctx->fail("fs_crf_step: at most " + std::to_string(kMaxTileChannels) + " label channels");
+    if (!unary || !Q || !f1 || !f2 || !f3 || !val || !out) return ctx->fail("fs_crf_step: null argument");
     for (int l = 0; l < S; ++l)
         if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step: val must be the one-hot of the last label");
     const int r = ctx->r, hp = h + 2 * r, wp = w + 2 * r;
@@ -653,6 +658,7 @@ int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, 
     if (set_device(ctx)) return -1;
     if (!ctx->have_params || ctx->params.mode != 1) return ctx->fail("fs_crf_step_lr: call fs_set_lr_params first");
     if (B < 1 || h < 1 || w < 1 || S < 2 || S > kMaxLabels) return ctx->fail("fs_crf_step_lr: bad shape");
+    if (!unary || !Q || !f1 || !f2 || !f3 || !f4 || !val || !out) return ctx->fail("fs_crf_step_lr: null argument");
     for (int l = 0; l < S; ++l)
         if (val[l] != (l == S - 1 ? 1.0f : 0.0f)) return ctx->fail("fs_crf_step_lr: val must be the one-hot of the last label");
     const int r = ctx->r;
@@ -725,6 +731,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                            float *points, int64_t *patches, int32_t *edges, int64_t *surfaces, int32_t *num_surfaces)
 {
     if (check_batch(ctx, n)) return -1;
+    if (!depth || !rgb) return ctx->fail("fs_find_surfaces: depth and rgb are required");
     const size_t N = ctx->N();
     FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
     FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
@@ -790,6 +797,7 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
 {
     if (check_batch(ctx, n)) return -1;
     if (!ctx->have_params) return ctx->fail("fs_apply_crf: call fs_set_gauss_params first");
+    if (!labels || !depth || !rgb || !angles || !out) return ctx->fail("fs_apply_crf: null argument");
     const size_t N = ctx->N(), px = (size_t)n * N;
     // int64 labels -> int32 on the host (tiny), maximum per frame gives the channel count
     std::vector<int32_t> lab32(px);
@@ -798,7 +806,8 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
         int64_t mx = 0;
         for (size_t k = 0; k < N; ++k) {
             const int64_t v = labels[i * N + k];
-            if (v < 0) return ctx->fail("fs_apply_crf: negative label");
+            if (v < 0 || v > kMaxLabels - 2)
+                return ctx->fail("fs_apply_crf: label " + std::to_string(v) + " outside [0, " + std::to_string(kMaxLabels - 2) + "]");
             lab32[i * N + k] = (int32_t)v;
             if (v > mx) mx = v;
         }

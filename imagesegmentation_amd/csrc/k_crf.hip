@@ -286,42 +286,69 @@ constexpr int REC_MASK = 8, REC_LAB = REC_MASK + MASK_WORDS;
 constexpr int TILE_REC = REC_LAB + kMaxLabels;
 
 __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tw, int th,
-                                                              int grow, int32_t *__restrict__ recs,
-                                                              int32_t *__restrict__ max_active)
+                                                              int grow, int tiles_x, int tiles_y, int total_tiles,
+                                                              int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
 {
     __shared__ unsigned mask[MASK_WORDS];
-    const int frame = blockIdx.z;
+    // consecutive workgroups go to different XCDs (one L2 each): give every XCD a contiguous run of tiles so
+    // that the overlapping surroundings of neighbouring tiles are served by one L2
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= total_tiles) return;
+    const int frame = tile / (tiles_x * tiles_y), tin = tile - frame * (tiles_x * tiles_y);
+    const int tile_y = tin / tiles_x, tile_x = tin - tile_y * tiles_x;
     const int32_t *P = patches + (size_t)frame * H * W;
-    const int tiles_x = gridDim.x, tiles_y = gridDim.y;
-    int32_t *rec = recs + ((size_t)frame * tiles_x * tiles_y + (size_t)blockIdx.y * tiles_x + blockIdx.x) * TILE_REC;
+    int32_t *rec = recs + (size_t)tile * TILE_REC;
     if (threadIdx.x < MASK_WORDS) mask[threadIdx.x] = 0u;
     __syncthreads();
-    const int xa = max(0, (int)blockIdx.x * tw - grow), xb = min(W, (int)(blockIdx.x + 1) * tw + grow);
-    const int ya = max(0, (int)blockIdx.y * th - grow), yb = min(H, (int)(blockIdx.y + 1) * th + grow);
+    const int xa = max(0, tile_x * tw - grow), xb = min(W, (tile_x + 1) * tw + grow);
+    const int ya = max(0, tile_y * th - grow), yb = min(H, (tile_y + 1) * th + grow);
     const int rw = xb - xa;
     const int total = rw * (yb - ya);
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int yy = i / rw, xx = i - yy * rw;
-        const int lab = P[(size_t)(ya + yy) * W + xa + xx];
-        if (lab > 0 && lab < kMaxLabels) {
-            const unsigned bit = 1u << (lab & 31);
-            if (!(mask[lab >> 5] & bit)) atomicOr(&mask[lab >> 5], bit);
+    const float inv_rw = 1.0f / (float)rw;
+    constexpr int LU = 6;   // loads in flight per lane: the scan is bound by load latency, not by bandwidth
+    for (int i0 = 0; i0 < total; i0 += 256 * LU) {   // uniform trip count: the lane exchange below needs every lane
+        int lab[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int i = i0 + u * 256 + (int)threadIdx.x;
+            lab[u] = 0;
+            if (i < total) {
+                int yy = (int)(((float)i + 0.5f) * inv_rw), xx = i - yy * rw;   // i / rw without the integer divide
+                if (xx < 0) { --yy; xx += rw; }
+                else if (xx >= rw) { ++yy; xx -= rw; }
+                lab[u] = P[(size_t)(ya + yy) * W + xa + xx];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            // patches are wide: a lane whose neighbour one lane down (within its group of 16) holds the
+            // same label leaves the bit to that lane
+            const int prev = __builtin_amdgcn_update_dpp(-1, lab[u], 0x111, 0xf, 0xf, false);
+            if (lab[u] > 0 && lab[u] < kMaxLabels && lab[u] != prev) {
+                const unsigned bit = 1u << (lab[u] & 31);
+                if (!(mask[lab[u] >> 5] & bit)) atomicOr(&mask[lab[u] >> 5], bit);
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < MASK_WORDS) {   // one lane per mask word: its labels follow those of the words below it
+        const int w = threadIdx.x;
+        unsigned m = mask[w];
         int A = 0;
-        for (int w = 0; w < MASK_WORDS; ++w) {
-            unsigned m = mask[w];
-            rec[REC_MASK + w] = (int32_t)m;
-            while (m) {
-                const int b = __ffs(m) - 1;
-                rec[REC_LAB + A++] = w * 32 + b;
-                m &= m - 1;
-            }
+        for (int k = 0; k < w; ++k) A += __popc(mask[k]);
+        rec[REC_MASK + w] = (int32_t)m;
+        while (m) {
+            const int b = __ffs(m) - 1;
+            rec[REC_LAB + A++] = w * 32 + b;
+            m &= m - 1;
         }
-        rec[0] = A;
-        atomicMax(max_active + frame, A);
+        if (w == MASK_WORDS - 1) {
+            rec[0] = A;
+            // the maximum only grows: a (possibly stale) read filters out nearly every block, which matters
+            // because atomics of all frames land on a handful of cache lines and serialise there
+            if (A > __hip_atomic_load(max_active + frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_active + frame, A);
+        }
     }
 }
 
@@ -1028,7 +1055,9 @@ void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int til
                             int32_t *max_active, hipStream_t st)
 {
     const int tx = (W + tile_w - 1) / tile_w, ty = (H + tile_h - 1) / tile_h;
-    hipLaunchKernelGGL(crf_tile_active_kernel, dim3(tx, ty, n), dim3(256), 0, st, patches, H, W, tile_w, tile_h, grow, recs, max_active);
+    const int total = tx * ty * n;
+    hipLaunchKernelGGL(crf_tile_active_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, st, patches, H, W, tile_w, tile_h, grow, tx, ty,
+                       total, recs, max_active);
 }
 
 // tile height of the fused kernel for a window radius: 16 rows while the staged tile fits in LDS, else 8
