@@ -612,6 +612,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // is what bounds the plane-based kernel; the six feature values of tile + halo fit in LDS next
 // to Q, so here every lane evaluates sim(p, q) itself:
 //   sim = w1'[o] 2^-(K1 u) + w2'[o] 2^-(K2 u + |dc'|^2) + w3'[o] 2^-(K3 u + |da'|^2) + bias
+//   (when the weights do not depend on the offset and the bias is 0: sim = sum of 2^-(exponent - log2 w'))
 //   (c', a': colours and angles as stored by crf_pack_features, scaled by the root of their coefficient)
 //   u = ((dq - dp) / (dp + dq))^2  (0 when both depths are 0),
 // the reference's three Gaussian kernels (find_surfaces.py:343-355) with the normalisers and
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
 // On the first update Q is synthesised from the patch labels
 // (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
 // ---------------------------------------------------------------------------
-struct FusedConsts { float K1, K2, K3, evidence; float uw[4]; };   // uw: the window's common (w1', w2', w3', bias) when uniform
+struct FusedConsts { float K1, K2, K3, evidence; float uw[4]; };   // uw: -log2 of the window's common (w1', w2', w3') when uniform
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
@@ -688,10 +689,12 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         // UNIFORM: every offset of the window carries the same constants (the trained position thetas
         // underflow to 0), so they live in four scalar registers, switched off per row where a neighbour
         // row is out of a pixel's reach and at the centre; no table loads compete with the LDS reads
-        const float m0 = jr <= 2 * r ? 1.0f : 0.0f, m1 = jr >= 1 ? 1.0f : 0.0f;
-        const float4 u0 = make_float4(K.uw[0] * m0, K.uw[1] * m0, K.uw[2] * m0, K.uw[3] * m0);
-        const float4 u1 = make_float4(K.uw[0] * m1, K.uw[1] * m1, K.uw[2] * m1, K.uw[3] * m1);
-        const float c0 = jr == r ? 0.0f : 1.0f, c1 = jr == r + 1 ? 0.0f : 1.0f;
+        // (uw holds -log2 of the three weights: they join the exponents, w 2^-x = 2^-(x - log2 w), and a
+        // switched-off position is an exponent of +inf, i.e. a similarity of exactly 0)
+        const float kOff = __builtin_inff();
+        const bool on0 = jr <= 2 * r, on1 = jr >= 1;
+        const float4 u0 = make_float4(on0 ? K.uw[0] : kOff, on0 ? K.uw[1] : kOff, on0 ? K.uw[2] : kOff, 0.0f);
+        const float4 u1 = make_float4(on1 ? K.uw[0] : kOff, on1 ? K.uw[1] : kOff, on1 ? K.uw[2] : kOff, 0.0f);
 #pragma unroll
         for (int dx = -r; dx <= r; ++dx) {
             const Operands o = nxt;
@@ -703,17 +706,19 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
             if (UNIFORM) {
                 w0 = u0; w1 = u1;
                 if (dx == 0) {
-                    w0 = make_float4(u0.x * c0, u0.y * c0, u0.z * c0, u0.w * c0);
-                    w1 = make_float4(u1.x * c1, u1.y * c1, u1.z * c1, u1.w * c1);
+                    if (jr == r) w0 = make_float4(kOff, kOff, kOff, 0.0f);
+                    if (jr == r + 1) w1 = make_float4(kOff, kOff, kOff, 0.0f);
                 }
             } else {
                 w0 = wrow0[dx]; w1 = wrow1[dx];                                       // wave-uniform (scalar loads)
             }
             const f2 dj = f2{fa.x, fa.x};
             const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
-            const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1, e0 * e0));
+            constexpr bool FOLD = UNIFORM && MODE == 0;     // weights folded into the exponents
+            const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1,
+                              FOLD ? __builtin_elementwise_fma(e0, e0, f2{w0.y, w1.y}) : e0 * e0));
             const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
-            const f2 ea = __builtin_elementwise_fma(g1, g1, g0 * g0);
+            const f2 ea = __builtin_elementwise_fma(g1, g1, FOLD ? __builtin_elementwise_fma(g0, g0, f2{w0.z, w1.z}) : g0 * g0);
             f2 sv;
             if (MODE == 0) {
                 // Gaussian kernels (find_surfaces.py:339-355); wtab = (w1', w2', w3', bias)
@@ -721,15 +726,18 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
                 const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
                 const f2 t = (dj - cd) * inv;
                 const f2 u = t * t;
-                const f2 x1 = f2{K.K1, K.K1} * u;
+                const f2 x1 = FOLD ? __builtin_elementwise_fma(f2{K.K1, K.K1}, u, f2{w0.x, w1.x}) : f2{K.K1, K.K1} * u;
                 const f2 x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);     // colours and angles are stored pre-scaled
                 const f2 x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
                 const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
                 const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
                 const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
-                sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
-                     __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
-                     __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
+                if (FOLD)
+                    sv = (s1 + s2) + s3;
+                else
+                    sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
+                         __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
+                         __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
             } else {
                 // linear similarity (find_surfaces.py:406-422); wtab = (6 c1, 2 c2, c3 / 50, bias + c4 |offset| / 40);
                 // the depth difference is relative to the lane's own depth (cinv = 1 / d_p, 0 if d_p == 0)
@@ -1098,8 +1106,12 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
     K.evidence = P.evidence;
     // the window's constants are uniform when the position terms vanish (as with the trained parameters)
-    const bool uniform = P.mode == 0 && P.t11 == 0.0f && P.t21 == 0.0f && P.t31 == 0.0f;
-    K.uw[0] = P.w1; K.uw[1] = P.w2; K.uw[2] = P.w3; K.uw[3] = P.bias;
+    // and that variant also wants weights with a logarithm (non-negative) and no bias, as the loader of the
+    // trained parameters guarantees (find_surfaces.py:221-226); anything else takes the table-driven kernels
+    const bool uniform = P.mode == 0 && P.t11 == 0.0f && P.t21 == 0.0f && P.t31 == 0.0f && P.w1 >= 0.0f && P.w2 >= 0.0f &&
+                         P.w3 >= 0.0f && P.bias == 0.0f;
+    K.uw[0] = (float)-std::log2((double)P.w1); K.uw[1] = (float)-std::log2((double)P.w2); K.uw[2] = (float)-std::log2((double)P.w3);
+    K.uw[3] = 0.0f;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
     const int th = crf_fused_tile_height(g.r);
 #define FS_FUSED_CASES_U(RR, THH)                                                                            \
