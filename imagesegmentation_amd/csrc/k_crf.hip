@@ -679,98 +679,124 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         if (NQ > 1) o.q1 = rw.Q1[k];
         return o;
     };
+    constexpr bool FOLD = UNIFORM && MODE == 0;     // weights folded into the exponents
+    const float kOff = __builtin_inff();
+    // one window position: neighbour `a` seen from row 0 of the pair with constants w0, neighbour `b` from row 1 with w1
+    auto step = [&](const Operands &a, const Operands &b, const float4 &w0, const float4 &w1) {
+        const f2 dj = f2{a.fa.x, b.fa.x};
+        const f2 e0 = f2{a.fa.y, b.fa.y} - cr, e1 = f2{a.fa.z, b.fa.z} - cg, e2 = f2{a.fa.w, b.fa.w} - cb;
+        const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1,
+                          FOLD ? __builtin_elementwise_fma(e0, e0, f2{w0.y, w1.y}) : e0 * e0));
+        const f2 g0 = f2{a.fb.x, b.fb.x} - ca0, g1 = f2{a.fb.y, b.fb.y} - ca1;
+        const f2 ea = __builtin_elementwise_fma(g1, g1, FOLD ? __builtin_elementwise_fma(g0, g0, f2{w0.z, w1.z}) : g0 * g0);
+        f2 sv;
+        if (MODE == 0) {
+            // Gaussian kernels (find_surfaces.py:339-355); wtab = (w1', w2', w3', bias)
+            const f2 den = cd + dj;
+            const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            const f2 t = (dj - cd) * inv;
+            const f2 u = t * t;
+            const f2 x1 = FOLD ? __builtin_elementwise_fma(f2{K.K1, K.K1}, u, f2{w0.x, w1.x}) : f2{K.K1, K.K1} * u;
+            const f2 x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);     // colours and angles are stored pre-scaled
+            const f2 x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
+            const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
+            const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
+            const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
+            if (FOLD)
+                sv = (s1 + s2) + s3;
+            else
+                sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
+                     __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
+                     __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
+        } else {
+            // linear similarity (find_surfaces.py:406-422); wtab = (6 c1, 2 c2, c3 / 50, bias + c4 |offset| / 40);
+            // the depth difference is relative to the lane's own depth (cinv = 1 / d_p, 0 if d_p == 0)
+            const f2 t = (dj - cd) * cinv;
+            const f2 at = f2{__builtin_fabsf(t.x), __builtin_fabsf(t.y)};
+            const f2 sa = f2{__builtin_amdgcn_sqrtf(ea.x), __builtin_amdgcn_sqrtf(ea.y)};
+            const f2 sc = f2{__builtin_amdgcn_sqrtf(ec.x), __builtin_amdgcn_sqrtf(ec.y)};
+            sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, sc,
+                 __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
+                 __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float sI = i == 0 ? sv.x : sv.y;
+            const float4 q0 = i == 0 ? a.q0 : b.q0, q1 = i == 0 ? a.q1 : b.q1;
+            acc[i][0] = fmaf(sI, q0.x, acc[i][0]);
+            acc[i][1] = fmaf(sI, q0.y, acc[i][1]);
+            acc[i][2] = fmaf(sI, q0.z, acc[i][2]);
+            acc[i][3] = fmaf(sI, q0.w, acc[i][3]);
+            if (NQ > 1) {
+                acc[i][4] = fmaf(sI, q1.x, acc[i][4]);
+                acc[i][5] = fmaf(sI, q1.y, acc[i][5]);
+                acc[i][6] = fmaf(sI, q1.z, acc[i][6]);
+                acc[i][7] = fmaf(sI, q1.w, acc[i][7]);
+            }
+        }
+    };
+    // UNIFORM: every offset of the window carries the same constants (the trained position thetas underflow
+    // to 0), so they live in scalar registers and no table loads compete with the LDS reads.  uw holds -log2
+    // of the three weights: they join the exponents, w 2^-x = 2^-(x - log2 w); the centre of the window is
+    // switched off with an exponent of +inf, i.e. a similarity of exactly 0.
+    const float4 uon = make_float4(K.uw[0], K.uw[1], K.uw[2], 0.0f), uoff = make_float4(kOff, kOff, kOff, 0.0f);
+    // neighbour rows 1 .. 2r of the region lie in the window of both rows of the pair: row 0 sees row jr at
+    // dy = jr - r, row 1 at dy = jr - r - 1, and one read serves both
     const int last_row = 1 + 2 * r;
-    Row cur = row_of(0);
+    Row cur = row_of(1);
     Operands nxt = read(cur, 0);
-    for (int jr = 0; jr <= last_row; ++jr) {
-        const Row below = row_of(jr < last_row ? jr + 1 : last_row);
-        const float4 *wrow0 = wtab + (jr <= 2 * r ? jr : kw) * kw + r;          // weights of row 0's dy (zero row when out of reach)
-        const float4 *wrow1 = wtab + (jr >= 1 ? jr - 1 : kw) * kw + r;          // ... and of row 1's
-        // UNIFORM: every offset of the window carries the same constants (the trained position thetas
-        // underflow to 0), so they live in four scalar registers, switched off per row where a neighbour
-        // row is out of a pixel's reach and at the centre; no table loads compete with the LDS reads
-        // (uw holds -log2 of the three weights: they join the exponents, w 2^-x = 2^-(x - log2 w), and a
-        // switched-off position is an exponent of +inf, i.e. a similarity of exactly 0)
-        const float kOff = __builtin_inff();
-        const bool on0 = jr <= 2 * r, on1 = jr >= 1;
-        const float4 u0 = make_float4(on0 ? K.uw[0] : kOff, on0 ? K.uw[1] : kOff, on0 ? K.uw[2] : kOff, 0.0f);
-        const float4 u1 = make_float4(on1 ? K.uw[0] : kOff, on1 ? K.uw[1] : kOff, on1 ? K.uw[2] : kOff, 0.0f);
+#pragma unroll 1
+    for (int jr = 1; jr <= 2 * r; ++jr) {
+        const Row below = row_of(jr < 2 * r ? jr + 1 : 0);                        // after the shared rows: the top row (below)
+        const float4 *wrow0 = wtab + jr * kw + r, *wrow1 = wtab + (jr - 1) * kw + r;
 #pragma unroll
         for (int dx = -r; dx <= r; ++dx) {
             const Operands o = nxt;
             nxt = dx < r ? read(cur, dx + r + 1) : read(below, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 fa = o.fa, q0 = o.q0, q1 = o.q1;
-            const float2 fb = o.fb;
             float4 w0, w1;
             if (UNIFORM) {
-                w0 = u0; w1 = u1;
+                w0 = uon; w1 = uon;
                 if (dx == 0) {
-                    if (jr == r) w0 = make_float4(kOff, kOff, kOff, 0.0f);
-                    if (jr == r + 1) w1 = make_float4(kOff, kOff, kOff, 0.0f);
+                    if (jr == r) w0 = uoff;
+                    if (jr == r + 1) w1 = uoff;
                 }
             } else {
                 w0 = wrow0[dx]; w1 = wrow1[dx];                                       // wave-uniform (scalar loads)
             }
-            const f2 dj = f2{fa.x, fa.x};
-            const f2 e0 = f2{fa.y, fa.y} - cr, e1 = f2{fa.z, fa.z} - cg, e2 = f2{fa.w, fa.w} - cb;
-            constexpr bool FOLD = UNIFORM && MODE == 0;     // weights folded into the exponents
-            const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1,
-                              FOLD ? __builtin_elementwise_fma(e0, e0, f2{w0.y, w1.y}) : e0 * e0));
-            const f2 g0 = f2{fb.x, fb.x} - ca0, g1 = f2{fb.y, fb.y} - ca1;
-            const f2 ea = __builtin_elementwise_fma(g1, g1, FOLD ? __builtin_elementwise_fma(g0, g0, f2{w0.z, w1.z}) : g0 * g0);
-            f2 sv;
-            if (MODE == 0) {
-                // Gaussian kernels (find_surfaces.py:339-355); wtab = (w1', w2', w3', bias)
-                const f2 den = cd + dj;
-                const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                const f2 t = (dj - cd) * inv;
-                const f2 u = t * t;
-                const f2 x1 = FOLD ? __builtin_elementwise_fma(f2{K.K1, K.K1}, u, f2{w0.x, w1.x}) : f2{K.K1, K.K1} * u;
-                const f2 x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);     // colours and angles are stored pre-scaled
-                const f2 x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
-                const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
-                const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
-                const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
-                if (FOLD)
-                    sv = (s1 + s2) + s3;
-                else
-                    sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, s3,
-                         __builtin_elementwise_fma(f2{w0.y, w1.y}, s2,
-                         __builtin_elementwise_fma(f2{w0.x, w1.x}, s1, f2{w0.w, w1.w})));
-            } else {
-                // linear similarity (find_surfaces.py:406-422); wtab = (6 c1, 2 c2, c3 / 50, bias + c4 |offset| / 40);
-                // the depth difference is relative to the lane's own depth (cinv = 1 / d_p, 0 if d_p == 0)
-                const f2 t = (dj - cd) * cinv;
-                const f2 at = f2{__builtin_fabsf(t.x), __builtin_fabsf(t.y)};
-                const f2 sa = f2{__builtin_amdgcn_sqrtf(ea.x), __builtin_amdgcn_sqrtf(ea.y)};
-                const f2 sc = f2{__builtin_amdgcn_sqrtf(ec.x), __builtin_amdgcn_sqrtf(ec.y)};
-                sv = __builtin_elementwise_fma(f2{w0.z, w1.z}, sc,
-                     __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
-                     __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float sI = i == 0 ? sv.x : sv.y;
-                acc[i][0] = fmaf(sI, q0.x, acc[i][0]);
-                acc[i][1] = fmaf(sI, q0.y, acc[i][1]);
-                acc[i][2] = fmaf(sI, q0.z, acc[i][2]);
-                acc[i][3] = fmaf(sI, q0.w, acc[i][3]);
-                if (NQ > 1) {
-                    acc[i][4] = fmaf(sI, q1.x, acc[i][4]);
-                    acc[i][5] = fmaf(sI, q1.y, acc[i][5]);
-                    acc[i][6] = fmaf(sI, q1.z, acc[i][6]);
-                    acc[i][7] = fmaf(sI, q1.w, acc[i][7]);
-                }
-            }
+            step(o, o, w0, w1);
             __builtin_amdgcn_sched_barrier(0);
         }
         cur = below;
     }
+    // the two rows that only one row of the pair reaches go through together: row 0 of the pair takes region
+    // row 0 (dy = -r), row 1 takes region row 2r+1 (dy = +r)
+    {
+        const Row bot = row_of(last_row);
+        Operands nb = read(bot, 0);
+        const float4 *wrow0 = wtab + r, *wrow1 = wtab + 2 * r * kw + r;
+#pragma unroll 1
+        for (int dx = -r; dx <= r; ++dx) {
+            const Operands oa = nxt, ob = nb;
+            if (dx < r) {
+                nxt = read(cur, dx + r + 1);
+                nb = read(bot, dx + r + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 w0, w1;
+            if (UNIFORM) {
+                w0 = uon; w1 = uon;
+            } else {
+                w0 = wrow0[dx]; w1 = wrow1[dx];
+            }
+            step(oa, ob, w0, w1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 template <int R, int TH, int NCH, int MODE, bool UNIFORM>
-__global__ __launch_bounds__(256) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
+__global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last,
                                                              int nframes)
 {
