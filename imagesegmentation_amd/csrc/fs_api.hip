@@ -148,9 +148,9 @@ int build_pos_terms(fs_ctx *ctx)
     FS_HIP(hipMemcpy(ctx->pos_terms.p, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
     // per-offset constants of the fused update over the full window: (w1', w2', w3', bias) with
     // w_k' = w_k * exp(-position term of kernel k); zeros at the centre (excluded from the message,
-    // find_surfaces.py:300-302) and in one extra row used for neighbour rows out of a pixel's reach
+    // find_surfaces.py:300-302)
     const int kw = 2 * r + 1;
-    std::vector<float> wt((size_t)4 * (kw + 1) * kw, 0.0f);
+    std::vector<float> wt((size_t)4 * kw * kw, 0.0f);
     for (int dy = -r; dy <= r; ++dy)
         for (int dx = -r; dx <= r; ++dx) {
             if (dy == 0 && dx == 0) continue;

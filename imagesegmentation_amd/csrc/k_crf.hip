@@ -635,9 +635,11 @@ constexpr int FTW = 32;                       // tile width of the fused kernel
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
 // from the staged chunk: acc[i][k] += sum over the window of sim(pixel i, neighbour) * Q_neighbour[k].
-// Both rows are carried as packed pairs, one v_pk_* instruction per operation.  wtab holds, per window
-// offset, (w1', w2', w3', bias) with zeros at the centre and in one extra row that serves the row of
-// the pair that a neighbour row does not reach, so no masking is left in the loop.
+// Both rows are carried as packed pairs, one v_pk_* instruction per operation.  The 2r region rows that
+// lie in both windows are read once for the pair; the topmost row (reached only by row 0) and the
+// bottommost (only by row 1) go through one extra pass together, each half of the pair with its own
+// neighbour, so no arithmetic is spent on positions outside a window.  wtab holds, per window offset,
+// (w1', w2', w3', bias) with zeros at the centre.
 // The relative depth difference divides by (d_p + d_q): a lane whose own depth is 0 may produce
 // NaN here; its result is overridden afterwards (Q[depth == 0]) and never read.
 template <int R, int NQ, int MODE, bool UNIFORM>
@@ -657,7 +659,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
     const f2 cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
     (void)cinv;
-    // neighbour rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees it at dy = jr - r - i.
+    // region rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees row jr at dy = jr - r - i.
     // The operands of the next window position are read from LDS before the arithmetic of the current
     // one starts (the scheduling barriers keep that order), so the read latency hides behind ~150 cycles
     // of vector work of the same wave instead of stalling it.
@@ -775,7 +777,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         const Row bot = row_of(last_row);
         Operands nb = read(bot, 0);
         const float4 *wrow0 = wtab + r, *wrow1 = wtab + 2 * r * kw + r;
-#pragma unroll 1
+#pragma unroll 3
         for (int dx = -r; dx <= r; ++dx) {
             const Operands oa = nxt, ob = nb;
             if (dx < r) {
