@@ -425,11 +425,10 @@ __device__ __forceinline__ void stage_q(float4 *lds4, const int *s_list, const f
 // m[c] = message of channel c (c < CE).
 template <int NC, bool COMPACT>
 __device__ __forceinline__ void finish_pixel(float (&m)[NC], const int *s_list, const CrfFrameDesc &d, int S, size_t No,
-                                             size_t wi, unsigned p, bool invalid, float weight, float evidence, int last)
+                                             size_t wi, int own, bool invalid, float weight, float evidence, int last)
 {
     const int CE = s_list[0], n_rest = s_list[1], rep_pos = s_list[2];
     const float pv = (float)(1.0 / (double)(S - 1));
-    const int own = d.patches ? d.patches[p] : 0;
     // evidence of the constant "unassigned" input: evidence * onehot(S-1), 0.00005 for the Gaussian similarity
     // (find_surfaces.py:356-357, 451-452), the auxiliary weight for the logistic-regression one (:424-425)
     // total over all S labels (the representative counts n_rest times), compensated so that
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        finish_pixel<NCH * CH, false>(m, s_list, d, S, No, wi[i], p[i], d.depth_raw && !valid[i], weight, evidence, last);
+        finish_pixel<NCH * CH, false>(m, s_list, d, S, No, wi[i], d.patches ? d.patches[p[i]] : 0, d.depth_raw && !valid[i], weight, evidence, last);
     }
 }
 
@@ -807,6 +806,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     extern __shared__ float4 lds4[];          // [2][LH][LW] Q quads | [LH][LW] (d,r,g,b) | [LH][LW] (a0,a1) as float2
     __shared__ int s_list[TILE_REC];
     __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
+    __shared__ int32_t s_nmask[15 * MASK_WORDS];   // label masks of those tiles
 
     // Workgroups are dealt to the 8 XCDs round-robin by their linear id; each XCD has its own L2.  The
     // tiles are therefore numbered so that an XCD receives a contiguous run of them (whole frames, mostly):
@@ -830,9 +830,6 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     float4 *featA = lds4 + 2 * plane4;
     float2 *featB = reinterpret_cast<float2 *>(featA + plane4);
 
-    build_channel_list<256>(s_list, d.tile_recs, by * tiles_x + bx, S);
-    const int CE = s_list[0];
-
     // ---- per-lane pixel pair: column lane & 31, rows (wave, lane half) ----
     const int col = lane & 31, half = lane >> 5;
     // TH = 16: wave covers rows 4*wv .. 4*wv+3, half 0 -> rows 4wv, 4wv+1; half 1 -> 4wv+2, 4wv+3
@@ -840,8 +837,25 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int trow = TH == 16 ? wv * 4 + half * 2 : wv * 2;
     const bool lane_on = TH == 16 || half == 0;
     const int gx = ix0 + col;
+    const int staged = LH * LW;
+    constexpr int FU = 3;
+
+    // A tile's set-up is a chain of dependent global reads, and with two blocks per CU little else runs
+    // while a block waits on one.  Everything that needs only the tile's position is therefore requested in
+    // one go: the tile's label record, the label masks of the 5x3 tiles the staged region touches, the
+    // lane's own depths and patch labels, and the first half of the feature records.
+    const int32_t *rec = d.tile_recs + ((size_t)by * tiles_x + bx) * TILE_REC;
+    const int32_t rec_word = rec[tid];                       // count, mask and the first 256 - REC_LAB labels
+    const int listed_labels = rec[0];                        // (every lane: lane 0 rewrites the LDS copy below)
+    int32_t nb_word = 0;
+    if (!first && tid < 15 * MASK_WORDS) {
+        const int st = tid / MASK_WORDS, sy = by + st / 3 - 2, sx = bx + st % 3 - 1;
+        if (sy >= 0 && sy < tiles_y && sx >= 0 && sx < tiles_x)
+            nb_word = d.tile_recs[((size_t)sy * tiles_x + sx) * TILE_REC + REC_MASK + (tid - st * MASK_WORDS)];
+    }
     bool ok[2], valid[2];
     unsigned p[2];
+    int own[2];
     bool any_work = false;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -849,40 +863,12 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         ok[i] = lane_on && gx < Wi && gy < Hi;
         p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
         valid[i] = ok[i] && d.depth_raw[p[i]] != 0;        // overridden pixels need no message
+        own[i] = ok[i] ? d.patches[p[i]] : 0;
         any_work |= valid[i];
     }
-    const bool wave_work = __ballot(any_work) != 0ull;
-
-    // a tile without a single valid depth (about one in five on sensor data) only writes the override values:
-    // nothing is staged for it
-    const bool block_work = __syncthreads_or(any_work) != 0;
-
-    // ---- where to read each of my channels in the nine tiles the staged region touches ----
-    if (block_work && !first && tid < 15) {
-        const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
-        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
-        } else {
-            const int32_t *rec = d.tile_recs + ((size_t)sy * tiles_x + sx) * TILE_REC;
-            const int32_t *m = rec + REC_MASK;
-            int rep = 1;                                            // representative of the source tile
-            while (rep < S - 1 && ((unsigned)m[rep >> 5] >> (rep & 31) & 1u)) ++rep;
-            for (int c = 0; c < CE; ++c) {
-                const int l = s_list[REC_LAB + c];
-                const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = listed ? l : rep;
-            }
-        }
-    }
-
-    // ---- features of tile + halo (zero outside the frame, like the reference's padded feature maps) ----
-    // flat index over the staged region, three pixels per thread and pass: all global loads of a pass are
-    // issued before the first LDS store waits for one of them
-    const int staged = LH * LW;
-    constexpr int FU = 3;
-    for (int i0 = block_work ? tid : staged; i0 < staged; i0 += 256 * FU) {
-        float4 fa[FU];
-        float2 fb[FU];
+    // features of tile + halo (zero outside the frame, like the reference's padded feature maps): flat index
+    // over the staged region, three pixels per thread and pass
+    auto load_features = [&](int i0, float4 (&fa)[FU], float2 (&fb)[FU]) {
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int i = i0 + u * 256;
@@ -896,6 +882,8 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                 fb[u] = d.featB[q];
             }
         }
+    };
+    auto store_features = [&](int i0, const float4 (&fa)[FU], const float2 (&fb)[FU]) {
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int i = i0 + u * 256;
@@ -903,6 +891,73 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                 featA[i] = fa[u];
                 featB[i] = fb[u];
             }
+        }
+    };
+    {
+        float4 fa[FU];
+        float2 fb[FU];
+        load_features(tid, fa, fb);
+        s_list[tid] = rec_word;
+        if (tid < 15 * MASK_WORDS) s_nmask[tid] = nb_word;
+        store_features(tid, fa, fb);
+    }
+    const bool wave_work = __ballot(any_work) != 0ull;
+    // a tile without a single valid depth (about one in five on sensor data) only writes the override values:
+    // nothing more is staged for it
+    const bool block_work = __syncthreads_or(any_work) != 0;
+
+    if (REC_LAB + listed_labels > 256) {                     // a label list longer than the first request (rare)
+        for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t] = rec[t];
+        __syncthreads();
+    }
+    // the rest of the features is on its way while one lane turns the record into the channel list
+    // [0, listed labels..., representative, S-1] and 15 lanes look up where to read each channel
+    float4 fa2[FU];
+    float2 fb2[FU];
+    if (block_work) load_features(tid + 256 * FU, fa2, fb2);
+    if (tid == 0) {
+        const int A = s_list[0];
+        int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
+        for (int i = A - 1; i >= 0; --i) labs[1 + i] = labs[i];
+        labs[0] = 0;
+        int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
+        if (n_rest > 0) {
+            int rp = 1;
+            while ((unsigned)m[rp >> 5] >> (rp & 31) & 1u) ++rp;   // smallest unlisted label in [1, S-2]
+            rep_pos = ce;
+            labs[ce++] = rp;
+        }
+        labs[ce++] = S - 1;
+        m[0] |= 1;
+        m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
+        s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
+    }
+    __syncthreads();
+    const int CE = s_list[0];
+
+    // ---- where to read each of my channels in the 5x3 tiles the staged region touches ----
+    if (block_work && !first && tid < 15) {
+        const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
+        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
+            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
+        } else {
+            const int32_t *m = s_nmask + tid * MASK_WORDS;
+            int rp = 1;                                             // representative of the source tile
+            while (rp < S - 1 && ((unsigned)m[rp >> 5] >> (rp & 31) & 1u)) ++rp;
+            for (int c = 0; c < CE; ++c) {
+                const int l = s_list[REC_LAB + c];
+                const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
+                s_src[tid][c] = listed ? l : rp;
+            }
+        }
+    }
+    if (block_work) {
+        store_features(tid + 256 * FU, fa2, fb2);
+        for (int i0 = tid + 2 * 256 * FU; i0 < staged; i0 += 256 * FU) {   // regions larger than 6 pixels per lane
+            float4 fa[FU];
+            float2 fb[FU];
+            load_features(i0, fa, fb);
+            store_features(i0, fa, fb);
         }
     }
 
@@ -974,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], p[i], !valid[i], weight, K.evidence, last);
+        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], own[i], !valid[i], weight, K.evidence, last);
     }
 }
 
