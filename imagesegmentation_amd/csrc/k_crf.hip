@@ -42,6 +42,12 @@
 #include <cmath>
 
 #include "fs_common.h"
+#ifndef FS_SKIPQ
+#define FS_SKIPQ 0
+#endif
+#ifndef FS_SKIPFIN
+#define FS_SKIPFIN 0
+#endif
 #ifndef FS_SKIPMAIN
 #define FS_SKIPMAIN 0
 #endif
@@ -604,6 +610,79 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
     }
 }
 
+// finish_pixel for the fused update (compact planes, synthesised unary, no potentials output), written so
+// that the work follows the tile's channel count: channel slots are visited in groups of four behind one
+// uniform test per group, and what depends on a slot's role comes from s_tab[c] = (multiplicity, evidence):
+// multiplicity 1 for a listed label, n_rest for the representative, 0 for an unused slot of the last group;
+// evidence of the constant "unassigned" input at the last channel (find_surfaces.py:356-357, 451-452).
+// Same formulas as finish_pixel; exp and the normalisation use v_exp_f32 and one reciprocal per pixel.
+template <int NC>
+__device__ __forceinline__ void finish_pixel_compact(float (&m)[NC], const int *s_list, const float2 *s_tab, const CrfFrameDesc &d,
+                                                     int S, size_t No, size_t wi, int own, bool invalid, float weight, int last)
+{
+    static_assert(NC % 4 == 0, "channel slots come in groups of four");
+    const int CE = s_list[0];
+    const float pv = (float)(1.0 / (double)(S - 1));
+    // total over all S labels (the representative counts n_rest times), compensated so that
+    // compatibility[l] = total - msg[l] keeps full relative accuracy
+    float tot = 0.0f, tot_lo = 0.0f;
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                const float2 role = s_tab[c];
+                m[c] = m[c] + role.y;
+                const float term = m[c] * role.x;
+                const float t = tot + term;
+                const float bp = t - tot;
+                tot_lo += (tot - (t - bp)) + (term - bp);
+                tot = t;
+            }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                const int lab = s_list[REC_LAB + c];
+                const float comp = (tot - m[c]) + tot_lo;          // Potts: sum of the other labels' messages (:297-298, 360)
+                float un = lab == 0 ? 10.0f : ((own != 0 && lab == own) ? 0.0f : 1.0f);   // :459-472
+                if (s_tab[c].x == 0.0f) un = INFINITY;             // unused slot: probability 0
+                m[c] = -(un + weight * comp);                      // :361
+                mx = fmaxf(mx, m[c]);
+            }
+        }
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                m[c] = __builtin_amdgcn_exp2f((m[c] - mx) * 1.44269504088896341f);   // softmax(-add), :363
+                den = fmaf(m[c], s_tab[c].x, den);
+            }
+        }
+    }
+    const float inv_den = 1.0f / den;
+    int best = 0;
+    float bestv = -1.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            const int lab = s_list[REC_LAB + c];
+            float q = m[c] * inv_den;
+            if (invalid) q = last ? 0.0f : (lab == 0 ? 0.0f : pv);   // Q[depth == 0] = prob | 0, :520-530
+            if (!last) d.Qout[(size_t)lab * No + wi] = q;
+            else if (q > bestv || (q == bestv && lab < best)) { bestv = q; best = lab; }   // first maximum, :531
+        }
+    }
+    if (last) d.surfaces[wi] = best == S - 1 ? 0 : best;                // :532
+}
+
 // ---------------------------------------------------------------------------
 // update with the similarity evaluated in the kernel (fused path).
 //
@@ -807,6 +886,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     __shared__ int s_list[TILE_REC];
     __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
     __shared__ int32_t s_nmask[15 * MASK_WORDS];   // label masks of those tiles
+    __shared__ float2 s_tab[NCH * CH];             // (multiplicity, evidence) of every channel slot
 
     // Workgroups are dealt to the 8 XCDs round-robin by their linear id; each XCD has its own L2.  The
     // tiles are therefore numbered so that an XCD receives a contiguous run of them (whole frames, mostly):
@@ -935,6 +1015,10 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     __syncthreads();
     const int CE = s_list[0];
 
+    if (tid < NCH * CH) {
+        const int n_rest = s_list[1], rep_pos = s_list[2];
+        s_tab[tid] = make_float2(tid >= CE ? 0.0f : (tid == rep_pos ? (float)n_rest : 1.0f), tid == CE - 1 ? K.evidence : 0.0f);
+    }
     // ---- where to read each of my channels in the 5x3 tiles the staged region touches ----
     if (block_work && !first && tid < 15) {
         const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
@@ -978,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
             if (ch > 0) __syncthreads();
             // ---- stage channels [ch*8, ch*8+8) of Q for tile + halo (same flat, batched scheme) ----
             constexpr int QU = 2;
-            for (int i0 = tid; i0 < staged; i0 += 256 * QU) {
+            for (int i0 = FS_SKIPQ ? staged : tid; i0 < staged; i0 += 256 * QU) {
                 float v[QU][CH];
 #pragma unroll
                 for (int u = 0; u < QU; ++u) {
@@ -1025,11 +1109,11 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (!ok[i]) continue;
+        if (!ok[i] || FS_SKIPFIN) continue;
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
-        finish_pixel<NCH * CH, true>(m, s_list, d, S, Ni, p[i], own[i], !valid[i], weight, K.evidence, last);
+        finish_pixel_compact<NCH * CH>(m, s_list, s_tab, d, S, Ni, p[i], own[i], !valid[i], weight, last);
     }
 }
 
