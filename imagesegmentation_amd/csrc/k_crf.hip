@@ -1071,21 +1071,26 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                     const int gy = iy0 - r + ly, gxx = ix0 - r + lx;
                     const bool in = i < staged && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
                     const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+                    const bool upper = CE - ch * CH > 4;     // channels 4..7 of the chunk are in use (uniform)
                     if (first) {
                         const int lab = in ? d.patches[q] : -1;
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
-                            const int l = ch * CH + k < CE ? s_list[REC_LAB + ch * CH + k] : -1;
-                            float x = 0.0f;
-                            if (lab >= 0 && l > 0) x = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
-                            v[u][k] = x;
+                            v[u][k] = 0.0f;
+                            if (k < 4 || upper) {
+                                const int l = ch * CH + k < CE ? s_list[REC_LAB + ch * CH + k] : -1;
+                                if (lab >= 0 && l > 0) v[u][k] = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
+                            }
                         }
                     } else {
                         const int st = in ? ((gy >> (TH == 16 ? 4 : 3)) - by + 2) * 3 + ((gxx >> 5) - bx + 1) : 0;
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
-                            const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
-                            v[u][k] = l >= 0 ? d.Qin[(size_t)l * Ni + q] : 0.0f;
+                            v[u][k] = 0.0f;
+                            if (k < 4 || upper) {
+                                const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
+                                if (l >= 0) v[u][k] = d.Qin[(size_t)l * Ni + q];
+                            }
                         }
                     }
                 }
