@@ -39,6 +39,7 @@ struct fs_ctx {
     // CRF buffers (one frame in flight)
     DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
     std::vector<CrfFrameDesc> descs_host;
+    DevBuf crf_queue;                  // tile queue of the fused CRF update
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
     // per-surface statistics (one frame in flight)
@@ -201,6 +202,7 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_newid.ensure(n * N * 4));
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
     FS_HIP(ctx->counts.ensure(2 * n * 4));
+    FS_HIP(ctx->crf_queue.ensure(kCrfQueueBytes));
     if (crf_fused_tile_height(ctx->r)) {
         int tx, ty;
         crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
@@ -373,7 +375,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             ScopedTimer t(ctx, G_ITER);
             for (const Launch &l : launches[(size_t)gi * iterations + it]) {
                 const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
-                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, ctx->stream)
+                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, ctx->crf_queue.as<unsigned>(), ctx->stream)
                                      : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }
@@ -430,7 +432,7 @@ void fs_destroy(fs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
-                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
                       &ctx->st_scratch, &ctx->st_out, &ctx->simH, &ctx->qa, &ctx->qb,
                       &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();

@@ -163,7 +163,10 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
                               size_t total, const CrfParams &P, hipStream_t st);
 // CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
 // planes of a tile's listed labels and of its representative are written (see k_crf.hip).
+// tile_queue: kCrfQueueBytes of device memory owned by the caller's context (the launch zeroes it; launches
+// that share it must be ordered on one stream).
+constexpr size_t kCrfQueueStride = 128, kCrfQueueBytes = 8 * kCrfQueueStride;
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
-                                 const CrfParams &P, const float *wtab, int mode, hipStream_t st);
+                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st);
 
 }  // namespace fs

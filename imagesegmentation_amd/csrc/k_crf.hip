@@ -878,10 +878,11 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
 template <int R, int TH, int NCH, int MODE, bool UNIFORM>
 __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last,
-                                                             int nframes)
+                                                             int nframes, unsigned *__restrict__ queue)
 {
     constexpr int CH = 8;
     static_assert(TH == 16 || TH == 8, "tile height");
+    __shared__ unsigned s_ticket;
     extern __shared__ float4 lds4[];          // [2][LH][LW] Q quads | [LH][LW] (d,r,g,b) | [LH][LW] (a0,a1) as float2
     __shared__ int s_list[TILE_REC];
     __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
@@ -895,8 +896,19 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int tiles_x = (g.Wi + FTW - 1) / FTW, tiles_y = (g.Hi + TH - 1) / TH;
     const unsigned tiles_total = (unsigned)tiles_x * tiles_y * nframes;
     const unsigned per_xcd = (tiles_total + 7u) / 8u;
-    const unsigned tile_id = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (tile_id >= tiles_total) return;
+    // Tile queue: one counter per XCD (128 bytes apart), zeroed before the launch.  A block takes tickets
+    // until its XCD's run of tiles is used up, which every block reaches; the ticket of the next tile is
+    // requested while the current tile is worked on.
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned *const my_queue = queue + xcd * (kCrfQueueStride / sizeof(unsigned));
+    unsigned next_ticket = 0;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(my_queue, 1u);
+    __syncthreads();
+  for (;;) {
+    const unsigned ticket = s_ticket;
+    const unsigned tile_id = xcd * per_xcd + ticket;
+    if (ticket >= per_xcd || tile_id >= tiles_total) break;
+    if (threadIdx.x == 0) next_ticket = atomicAdd(my_queue, 1u);
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
@@ -1120,6 +1132,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
         finish_pixel_compact<NCH * CH>(m, s_list, s_tab, d, S, Ni, p[i], own[i], !valid[i], weight, last);
     }
+    if (threadIdx.x == 0) s_ticket = next_ticket;     // every lane read the current ticket several barriers ago
+    __syncthreads();                                  // the next tile reuses the LDS
+  }
 }
 
 // depth u16 / rgb u8 / angles -> the float records the fused update stages: (d, r, g, b) and (a0, a1).
@@ -1156,12 +1171,12 @@ hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &
 
 template <int R, int TH, int NCH, int MODE, bool UNIFORM = false>
 hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
-                          float weight, int first, int last, hipStream_t st)
+                          float weight, int first, int last, unsigned *queue, hipStream_t st)
 {
     static size_t attr_lds = 0;                  // dynamic LDS the kernel has been allowed so far
     auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE, UNIFORM>;
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
-    const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8);
+    const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8 + 15 * MASK_WORDS + 2 * NCH * 8 + 4);
     if (lds + lds_static > 160 * 1024) return hipErrorInvalidValue;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1169,8 +1184,15 @@ hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom 
         attr_lds = lds;
     }
     const unsigned tiles = (unsigned)((g.Wi + FTW - 1) / FTW) * ((g.Hi + TH - 1) / TH) * nframes;
-    dim3 grid((tiles + 7u) / 8u * 8u);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last, nframes);
+    // Persistent blocks: as many as the chip holds at once (two per CU by LDS), each pulling tiles from the
+    // queue of its XCD until it is empty.  A block that ends and a new one that takes its place cost the CU
+    // several microseconds with half its waves missing; a block that just takes the next tile does not.
+    if (!queue) return hipErrorInvalidValue;
+    hipError_t qe = hipMemsetAsync(queue, 0, kCrfQueueBytes, st);
+    if (qe != hipSuccess) return qe;
+    const unsigned nblk = (tiles + 7u) / 8u * 8u;
+    dim3 grid(nblk < 512u ? nblk : 512u);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last, nframes, queue);
     return hipGetLastError();
 }
 
@@ -1268,7 +1290,7 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
 }
 
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
-                                 const CrfParams &P, const float *wtab, int mode, hipStream_t st)
+                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
@@ -1288,33 +1310,33 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     const int th = crf_fused_tile_height(g.r);
 #define FS_FUSED_CASES_U(RR, THH)                                                                            \
     switch (channel_class) {                                                                                 \
-    case 1: return launch_fused_t<RR, THH, 1, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
-    case 2: return launch_fused_t<RR, THH, 2, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
+    case 1: return launch_fused_t<RR, THH, 1, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);   \
+    case 2: return launch_fused_t<RR, THH, 2, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);   \
     case 3:                                                                                                  \
-    case 4: return launch_fused_t<RR, THH, 4, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
-    case 8: return launch_fused_t<RR, THH, 8, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st);   \
-    case 16: return launch_fused_t<RR, THH, 16, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, st); \
+    case 4: return launch_fused_t<RR, THH, 4, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);   \
+    case 8: return launch_fused_t<RR, THH, 8, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);   \
+    case 16: return launch_fused_t<RR, THH, 16, 0, true>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st); \
     default: return hipErrorInvalidValue;                                                                    \
     }
 #define FS_FUSED_CASES(RR, THH)                                                                              \
     switch (channel_class) {                                                                                 \
-    case 1: return launch_fused_t<RR, THH, 1, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 2: return launch_fused_t<RR, THH, 2, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
+    case 1: return launch_fused_t<RR, THH, 1, 0>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);         \
+    case 2: return launch_fused_t<RR, THH, 2, 0>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);         \
     case 3:                                                                                                  \
-    case 4: return launch_fused_t<RR, THH, 4, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 8: return launch_fused_t<RR, THH, 8, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);         \
-    case 16: return launch_fused_t<RR, THH, 16, 0>(descs, nframes, g, K, wt, P.weight, first, last, st);       \
+    case 4: return launch_fused_t<RR, THH, 4, 0>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);         \
+    case 8: return launch_fused_t<RR, THH, 8, 0>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);         \
+    case 16: return launch_fused_t<RR, THH, 16, 0>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);       \
     default: return hipErrorInvalidValue;                                                                    \
     }
     if (P.mode == 1) {
         // logistic-regression similarity: two channel classes only (it is not the tuned path)
         if (channel_class > 16) return hipErrorInvalidValue;
         if (th == 16)
-            return channel_class <= 2 ? launch_fused_t<0, 16, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, st)
-                                      : launch_fused_t<0, 16, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);
+            return channel_class <= 2 ? launch_fused_t<0, 16, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st)
+                                      : launch_fused_t<0, 16, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);
         if (th == 8)
-            return channel_class <= 2 ? launch_fused_t<0, 8, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, st)
-                                      : launch_fused_t<0, 8, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, st);
+            return channel_class <= 2 ? launch_fused_t<0, 8, 2, 1>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st)
+                                      : launch_fused_t<0, 8, 16, 1>(descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st);
         return hipErrorInvalidValue;
     }
     if (g.r == 7 && uniform) { FS_FUSED_CASES_U(7, 16) }
