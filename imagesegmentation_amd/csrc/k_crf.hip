@@ -896,19 +896,28 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int tiles_x = (g.Wi + FTW - 1) / FTW, tiles_y = (g.Hi + TH - 1) / TH;
     const unsigned tiles_total = (unsigned)tiles_x * tiles_y * nframes;
     const unsigned per_xcd = (tiles_total + 7u) / 8u;
-    // Tile queue: one counter per XCD (128 bytes apart), zeroed before the launch.  A block takes tickets
-    // until its XCD's run of tiles is used up, which every block reaches; the ticket of the next tile is
-    // requested while the current tile is worked on.
-    const unsigned xcd = blockIdx.x & 7u;
-    unsigned *const my_queue = queue + xcd * (kCrfQueueStride / sizeof(unsigned));
+    // Tile queue: one counter per XCD (128 bytes apart), zeroed before the launch.  A block takes tiles from
+    // the run of its own XCD and, once that is used up, from the runs of the others (frames differ in cost, so
+    // the runs do not end together), until all eight are empty, which every block reaches; the next tile is
+    // requested while the current one is worked on.
+    unsigned qi = blockIdx.x & 7u, queues_left = 8;          // lane 0's cursor over the queues
+    auto next_tile = [&]() -> unsigned {
+        while (queues_left) {
+            const unsigned t = atomicAdd(queue + qi * (kCrfQueueStride / sizeof(unsigned)), 1u);
+            const unsigned id = qi * per_xcd + t;
+            if (t < per_xcd && id < tiles_total) return id;
+            qi = (qi + 1u) & 7u;
+            --queues_left;
+        }
+        return 0xffffffffu;
+    };
     unsigned next_ticket = 0;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(my_queue, 1u);
+    if (threadIdx.x == 0) s_ticket = next_tile();
     __syncthreads();
   for (;;) {
-    const unsigned ticket = s_ticket;
-    const unsigned tile_id = xcd * per_xcd + ticket;
-    if (ticket >= per_xcd || tile_id >= tiles_total) break;
-    if (threadIdx.x == 0) next_ticket = atomicAdd(my_queue, 1u);
+    const unsigned tile_id = s_ticket;
+    if (tile_id == 0xffffffffu) break;
+    if (threadIdx.x == 0) next_ticket = next_tile();
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
