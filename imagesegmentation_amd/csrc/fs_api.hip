@@ -271,7 +271,9 @@ int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, int frames, float **plane0, s
     return 0;
 }
 
-constexpr int kCrfGroup = 37;   // frames per batched CRF launch (Q planes of one group are resident at a time)
+constexpr int kCrfGroup = 128;                 // most frames per batched CRF launch (few launches: each has a ramp and a tail)
+constexpr int kCrfGroupPlanes = 37;            // ... when the similarity planes of the group are kept as well
+constexpr size_t kCrfGroupBytes = (size_t)8 << 30;   // ... and most bytes of one Q buffer of a group
 constexpr int kPipeChunk = 16;  // frames per upload / compute / download step of the host-buffer entry point
 
 // CRF of n frames resident on the device: similarity planes, initial probabilities from
@@ -290,16 +292,29 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
     for (int i = 0; i < n; ++i)
         if (S[i] > kMaxLabels) return ctx->fail("frame has " + std::to_string(S[i]) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
-    const int G = n < kCrfGroup ? n : kCrfGroup;
+    // groups: consecutive frames, limited in number and in the size of their Q planes
+    std::vector<int> gstart{0};
+    size_t qmax = 0;
+    int gmax = 0;
+    {
+        const int cap = fused ? kCrfGroup : kCrfGroupPlanes;
+        size_t q = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t qi = (size_t)S[i] * N;
+            if (i > gstart.back() && (i - gstart.back() == cap || (q + qi) * sizeof(float) > kCrfGroupBytes)) {
+                gstart.push_back(i);
+                q = 0;
+            }
+            q += qi;
+            if (q > qmax) qmax = q;
+            if (i + 1 - gstart.back() > gmax) gmax = i + 1 - gstart.back();
+        }
+        gstart.push_back(n);
+    }
+    const int ngroups = (int)gstart.size() - 1;
     float *sim0 = nullptr;
     size_t sim_stride = 0;
-    if (!fused && ensure_sim(ctx, N, W, G, &sim0, &sim_stride)) return -1;
-    size_t qmax = 0;
-    for (int g0 = 0; g0 < n; g0 += G) {
-        size_t q = 0;
-        for (int i = g0; i < n && i < g0 + G; ++i) q += (size_t)S[i] * N;
-        if (q > qmax) qmax = q;
-    }
+    if (!fused && ensure_sim(ctx, N, W, gmax, &sim0, &sim_stride)) return -1;
     FS_HIP(ctx->qa.ensure(qmax * sizeof(float)));
     FS_HIP(ctx->qb.ensure(qmax * sizeof(float)));
 
@@ -307,9 +322,9 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     std::vector<CrfFrameDesc> &dh = ctx->descs_host;
     dh.assign((size_t)n * iterations, CrfFrameDesc{});
     struct Launch { size_t first; int count, cls; };
-    std::vector<std::vector<Launch>> launches(((size_t)n + G - 1) / G * iterations);
-    for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
-        const int gn = (n - g0) < G ? (n - g0) : G;
+    std::vector<std::vector<Launch>> launches((size_t)ngroups * iterations);
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
         std::vector<int> order(gn), cls(gn);
         std::vector<size_t> qoff(gn);
         size_t q = 0;
@@ -360,8 +375,8 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
         ScopedTimer t(ctx, G_SIM);
         launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->params, ctx->stream);
     }
-    for (int g0 = 0, gi = 0; g0 < n; g0 += G, ++gi) {
-        const int gn = (n - g0) < G ? (n - g0) : G;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
         if (!fused) {
             ScopedTimer t(ctx, G_SIM);
             launch_crf_sim(d_depth + (size_t)g0 * N, d_rgb + (size_t)g0 * N * 3, d_angles + (size_t)g0 * N * 2, ctx->params,
