@@ -169,7 +169,7 @@ def main():
         if not args.no_kernel_timing:
             ms, launches = ctx.get_timing(ITER)
             # Unit of the roofline figures: one mean-field update of one frame (launches are batched
-            # over up to 37 frames and split by channel class, so the per-frame update is the stable unit).
+            # over up to 128 frames and split by channel class, so the per-frame update is the stable unit).
             # Algorithmic bytes of one update of one frame: 24 B features + 4 B patch label + 4S read Q +
             # 4S write Q per pixel; the last update writes an int64 label instead of Q.  Three updates per frame.
             per_frame = N * ((28 + 8 * S) * 2 + (28 + 4 * S + 8))
