@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     };
     unsigned next_ticket = 0;
     if (threadIdx.x == 0) s_ticket = next_tile();
+    __builtin_amdgcn_s_setprio(2);
     __syncthreads();
   for (;;) {
     const unsigned tile_id = s_ticket;
@@ -1126,9 +1127,14 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
             }
             __syncthreads();
             if (wave_work && FS_SKIPMAIN == 0) {
+                // The arithmetic runs at low priority, set-up, staging and epilogue at high priority: the
+                // few instructions between a tile's memory requests then do not queue behind the other
+                // block's window walk, which shortens the phases in which a block contributes no arithmetic.
+                __builtin_amdgcn_s_setprio(0);
                 // 1..4 channels of the chunk need only the first quad plane (two thirds of all tiles)
                 if (CE - ch * CH <= 4) fused_accumulate<R, 1, MODE, UNIFORM>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
                 else fused_accumulate<R, 2, MODE, UNIFORM>(acc[ch], lds4, plane4, LW, trow, col, r, K, wtab);
+                __builtin_amdgcn_s_setprio(2);
             }
         }
     }

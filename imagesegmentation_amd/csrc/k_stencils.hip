@@ -221,9 +221,12 @@ __device__ __forceinline__ float curvature_total(const float (&tile)[TH + 8][TW 
             const float a2 = (g0 * g0 + g1 * g1) + g2 * g2;
             float dif1, dif2, score;
             if (FAST) {
+                // one reciprocal square root gives both |p_k - p_0| and its reciprocal (callers keep
+                // centres without depth, whose a2 can be 0, away from this path)
+                const float rs = __builtin_amdgcn_rsqf(a2);
                 dif1 = __builtin_amdgcn_sqrtf(a1);
-                dif2 = __builtin_amdgcn_sqrtf(a2);
-                score = (dif2 == 0.0f ? 0.0f : (dif1 + prevd) * __builtin_amdgcn_rcpf(dif2)) - 1.0f;
+                dif2 = a2 * rs;
+                score = (dif1 + prevd) * rs - 1.0f;
             } else {
                 dif1 = sqrtf(a1);
                 dif2 = sqrtf(a2);
@@ -263,10 +266,14 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
     const float dfy = (ay[r] * dc) * 0.5f;
     // Only the comparison with the threshold leaves this kernel (unless the caller asks for the
     // scores), so the score is first evaluated with the hardware's approximate sqrt and reciprocal
-    // (1 ulp each).  Every term (dif1 + dif2_prev) / dif2 - 1 is >= 0 (triangle inequality), so
+    // (1 ulp each; the reciprocal of |p_k - p_0| is a reciprocal square root of its square).  Every term (dif1 + dif2_prev) / dif2 - 1 is >= 0 (triangle inequality), so
     // near the threshold all ratios are <= 1 + threshold and the approximate total is within 4e-5
     // of the correctly rounded one; outside a band of 2e-4 the comparison is decided, inside it
     // the reference's correctly rounded evaluation is repeated (about one pixel in a thousand).
+    if (!scores && !(dc > 0.001f)) {                          // no depth: the mask is 0 whatever the score
+        mask[i] = 0;
+        return;
+    }
     float total;
     bool decided = false;
     if (!scores) {
