@@ -40,6 +40,7 @@ struct fs_ctx {
     DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
     std::vector<CrfFrameDesc> descs_host;
     DevBuf crf_queue;                  // tile queue of the fused CRF update
+    DevBuf curv_todo;                  // pixels whose curvature test needs the correctly rounded evaluation
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
     // per-surface statistics (one frame in flight)
@@ -183,6 +184,9 @@ int check_batch(fs_ctx *ctx, int n)
     return set_device(ctx);
 }
 
+// list capacity per frame: one pixel in 16 (about one in a thousand is undecided on sensor data)
+int curv_todo_cap(const fs_ctx *ctx) { return (int)(ctx->N() / 16); }
+
 int ensure_frame_buffers(fs_ctx *ctx)
 {
     const size_t n = ctx->max_batch, N = ctx->N();
@@ -203,6 +207,7 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
     FS_HIP(ctx->counts.ensure(2 * n * 4));
     FS_HIP(ctx->crf_queue.ensure(kCrfQueueBytes));
+    FS_HIP(ctx->curv_todo.ensure(curvature_todo_ints((int)n, curv_todo_cap(ctx)) * sizeof(int32_t)));
     if (crf_fused_tile_height(ctx->r)) {
         int tx, ty;
         crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
@@ -232,7 +237,8 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
     const float threshold = (float)(0.007003343675404672 * 10.5);   // find_surfaces.py:229
     {
         ScopedTimer t(ctx, G_STENCIL);
-        launch_curvature_mask(d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), threshold, d_curv, d_scores, n, H, W, ctx->stream);
+        launch_curvature_mask(d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), threshold, d_curv, d_scores, ctx->curv_todo.as<int32_t>(),
+                              curv_todo_cap(ctx), n, H, W, ctx->stream);
         launch_majority_edges(d_curv, d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), 3.0f, ctx->mask.as<uint8_t>(), d_edges, n, H, W, ctx->stream);
     }
     {
@@ -447,7 +453,7 @@ void fs_destroy(fs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
-                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
                       &ctx->st_scratch, &ctx->st_out, &ctx->simH, &ctx->qa, &ctx->qb,
                       &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();

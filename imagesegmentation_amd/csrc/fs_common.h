@@ -50,8 +50,11 @@ void launch_smooth_depth_f32(const float *depth, float *out, int n, int H, int W
 void launch_normals(const float *D, const float *tanx, const float *tany, float *points, float *normals,
                     float *raw_angles, int n, int H, int W, hipStream_t st);
 void launch_angle_filter(const float *raw_angles, const float *D, float *angles, int n, int H, int W, hipStream_t st);
+// todo: curvature_todo_ints(n, todo_cap) ints of work space for the pixels whose threshold test needs the
+// correctly rounded evaluation (a second, small kernel handles them); may be null
 void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
-                           float *scores, int n, int H, int W, hipStream_t st);
+                           float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st);
+size_t curvature_todo_ints(int n, int todo_cap);
 void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
                            uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st);
 // connected components (k_cc.hip)

@@ -201,37 +201,51 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
 // ax[c] = |tanx[c-1] - tanx[c+1]|, ay[r] = |tany[r-1] - tany[r+1]| are
 // precomputed on the host with the same fp32 operations.
 // ---------------------------------------------------------------------------
-template <bool FAST>
-__device__ __forceinline__ float curvature_total(const float (&tile)[TH + 8][TW + 8 + 1], int ty, int tx, float dc, float dfx, float dfy)
+// depth(oy, ox) = smoothed depth at the centre's row + oy, column + ox
+template <bool FAST, typename Depth>
+__device__ __forceinline__ float curvature_total(Depth depth, float dc, float dfx, float dfy)
 {
     constexpr int R = 4;
     float total = 0.0f;
     const int d0s[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     const int d1s[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    if (FAST) {
+        // the lateral parts of both distances do not depend on the direction: consecutive points are
+        // (dfx, dfy) apart, point k is k (dfx, dfy) from the centre
+        const float q = fmaf(dfx, dfx, dfy * dfy);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            float cur = 0.0f, prevd = 0.0f, pz = dc;
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const float nz = depth(-k * d0s[d], -k * d1s[d]);
+                const float e2 = nz - pz, g2 = nz - dc;
+                const float a1 = fmaf(e2, e2, q), a2 = fmaf(g2, g2, (float)(k * k) * q);
+                // one reciprocal square root gives both |p_k - p_0| and its reciprocal (callers keep
+                // centres without depth, whose a2 can be 0, away from this path)
+                const float rs = __builtin_amdgcn_rsqf(a2);
+                const float dif1 = __builtin_amdgcn_sqrtf(a1), dif2 = a2 * rs;
+                cur = cur + (fmaf(dif1 + prevd, rs, -1.0f));
+                total = total + cur;
+                prevd = dif2;
+                pz = nz;
+            }
+        }
+        return total;
+    }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
 #pragma unroll
         for (int k = 1; k <= R; ++k) {
             const float nx = dfx * (float)k, ny = dfy * (float)k;
-            const float nz = tile[ty + R - k * d0s[d]][tx + R - k * d1s[d]];
+            const float nz = depth(-k * d0s[d], -k * d1s[d]);
             const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
             const float a1 = (e0 * e0 + e1 * e1) + e2 * e2;
             const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
             const float a2 = (g0 * g0 + g1 * g1) + g2 * g2;
-            float dif1, dif2, score;
-            if (FAST) {
-                // one reciprocal square root gives both |p_k - p_0| and its reciprocal (callers keep
-                // centres without depth, whose a2 can be 0, away from this path)
-                const float rs = __builtin_amdgcn_rsqf(a2);
-                dif1 = __builtin_amdgcn_sqrtf(a1);
-                dif2 = a2 * rs;
-                score = (dif1 + prevd) * rs - 1.0f;
-            } else {
-                dif1 = sqrtf(a1);
-                dif2 = sqrtf(a2);
-                score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
-            }
+            const float dif1 = sqrtf(a1), dif2 = sqrtf(a2);
+            const float score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
             cur = cur + score;
             total = total + cur;
             prevd = dif2;
@@ -244,7 +258,7 @@ __device__ __forceinline__ float curvature_total(const float (&tile)[TH + 8][TW 
 __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restrict__ D, const float *__restrict__ ax,
                                                             const float *__restrict__ ay, float threshold,
                                                             uint8_t *__restrict__ mask, float *__restrict__ scores,
-                                                            int H, int W)
+                                                            int32_t *__restrict__ todo, int todo_cap, int H, int W)
 {
     constexpr int R = 4;
     __shared__ float tile[TH + 2 * R][TW + 2 * R + 1];
@@ -267,23 +281,57 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
     // Only the comparison with the threshold leaves this kernel (unless the caller asks for the
     // scores), so the score is first evaluated with the hardware's approximate sqrt and reciprocal
     // (1 ulp each; the reciprocal of |p_k - p_0| is a reciprocal square root of its square).  Every term (dif1 + dif2_prev) / dif2 - 1 is >= 0 (triangle inequality), so
-    // near the threshold all ratios are <= 1 + threshold and the approximate total is within 4e-5
-    // of the correctly rounded one; outside a band of 2e-4 the comparison is decided, inside it
+    // near the threshold all ratios are <= 1 + threshold and the approximate total (which also shares the
+    // lateral parts of the distances between the directions, another few 1e-7 per term) is within 1e-4
+    // of the correctly rounded one (worst case 80 weighted terms x 8e-7); outside a band of 1e-4 the comparison is decided, inside it
     // the reference's correctly rounded evaluation is repeated (about one pixel in a thousand).
     if (!scores && !(dc > 0.001f)) {                          // no depth: the mask is 0 whatever the score
         mask[i] = 0;
         return;
     }
+    // A wave with a single undecided lane would spend ten times the approximate evaluation on it, and about
+    // one wave in twenty has one: undecided pixels go to a per-frame list (todo = counts[frames], then lists[frames][todo_cap] of
+    // pixel indices) that curvature_exact_kernel works through with full waves; only when the list is full (or
+    // absent) the exact evaluation runs here.
+    auto at = [&](int oy, int ox) { return tile[ty + R + oy][tx + R + ox]; };
     float total;
     bool decided = false;
     if (!scores) {
-        total = curvature_total<true>(tile, ty, tx, dc, dfx, dfy);
-        decided = fabsf(total - threshold) > 2e-4f;           // false for NaN: then the exact evaluation decides
+        total = curvature_total<true>(at, dc, dfx, dfy);
+        decided = fabsf(total - threshold) > 1e-4f;           // false for NaN: then the exact evaluation decides
+        if (!decided && todo_cap > 0) {
+            const int slot = atomicAdd(todo + blockIdx.z, 1);
+            if (slot < todo_cap) {
+                todo[gridDim.z + (size_t)blockIdx.z * todo_cap + slot] = r * W + c;
+                return;
+            }
+        }
     }
-    if (!decided) total = curvature_total<false>(tile, ty, tx, dc, dfx, dfy);
+    if (!decided) total = curvature_total<false>(at, dc, dfx, dfy);
     if (scores) scores[i] = total;
     const uint8_t pix = total < threshold ? 1 : 0;
     mask[i] = dc > 0.001f ? pix : 0;
+}
+
+// The reference's correctly rounded evaluation for the pixels curvature_mask_kernel left undecided: one lane
+// per list entry, depths read from global memory (the entries are scattered over the frame).
+__global__ __launch_bounds__(256) void curvature_exact_kernel(const float *__restrict__ D, const float *__restrict__ ax,
+                                                              const float *__restrict__ ay, float threshold,
+                                                              uint8_t *__restrict__ mask, const int32_t *__restrict__ todo,
+                                                              int todo_cap, int H, int W)
+{
+    const int32_t *list = todo + gridDim.y + (size_t)blockIdx.y * todo_cap;
+    const int count = min(todo[blockIdx.y], todo_cap);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const int p = list[t], r = p / W, c = p - r * W;
+    const float *F = D + (size_t)blockIdx.y * H * W;
+    const float dc = F[p];
+    const float dfx = (ax[c] * dc) * 0.5f;
+    const float dfy = (ay[r] * dc) * 0.5f;
+    auto at = [&](int oy, int ox) { return F[p + oy * W + ox]; };   // the centre is at least 4 pixels inside the frame
+    const float total = curvature_total<false>(at, dc, dfx, dfy);
+    mask[(size_t)blockIdx.y * H * W + p] = (total < threshold && dc > 0.001f) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -368,10 +416,18 @@ void launch_angle_filter(const float *raw_angles, const float *D, float *angles,
     hipLaunchKernelGGL(angle_filter_kernel, tile_grid(n, H, W), dim3(NT), 0, st, raw_angles, D, angles, H, W);
 }
 void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
-                           float *scores, int n, int H, int W, hipStream_t st)
+                           float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, H, W);
+    if (scores || !todo || todo_cap < 256) {
+        hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, nullptr, 0, H, W);
+        return;
+    }
+    (void)hipMemsetAsync(todo, 0, (size_t)n * sizeof(int32_t), st);
+    hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, todo, todo_cap, H, W);
+    hipLaunchKernelGGL(curvature_exact_kernel, dim3((todo_cap + 255) / 256, n), dim3(256), 0, st, D, ax, ay, threshold, mask, todo,
+                       todo_cap, H, W);
 }
+size_t curvature_todo_ints(int n, int todo_cap) { return (size_t)n * (1 + (size_t)todo_cap); }
 void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
                            uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st)
 {
