@@ -6,12 +6,13 @@
 // order of each component's first pixel, components of <= 20 pixels removed.
 //
 // Algorithm (all integer, schedule independent):
-//   1. init    each wave labels 64 consecutive pixels of a row: a ballot of the
-//              mask gives every lane the start of its horizontal run, which
-//              becomes its parent (so horizontal unions inside a wave are free);
-//   2. merge   lock-free union-find with atomicMin: runs that continue across a
-//              wave boundary, and vertical neighbours (skipped when the pixel to
-//              the left already carries the same vertical link);
+//   1. local   components inside 64 x 16 tiles in LDS: a wave labels one tile row, a
+//              ballot of the mask gives every lane the start of its horizontal run,
+//              which becomes its parent (so horizontal unions are free); vertical
+//              neighbours are joined by a union-find with LDS atomicMin (skipped
+//              when the pixel to the left already carries the same link);
+//   2. border  the links across tile borders with the same union-find on the flat
+//              indices in global memory;
 //              the root of a tree is always its smallest flat index, i.e. the
 //              component's first pixel in raster order;
 //   3. flatten every pixel points at its root; per-root pixel counts with one
@@ -66,50 +67,115 @@ __device__ __forceinline__ void uf_union(int32_t *L, int a, int b)
     }
 }
 
-// T = uint8_t (binary mask) or int32_t (label image): pixels are connected when their values are
-// equal and non-zero.
-template <typename T>
-__global__ __launch_bounds__(CC_BLOCK) void cc_init_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
-                                                           int32_t *__restrict__ count, int N, int W)
+// ---- components inside a 64 x 16 tile, in LDS -------------------------------------------------------
+constexpr int LTW = 64, LTH = 16;            // one wave per tile row
+
+__device__ __forceinline__ int lds_parent(const int *L, int i)
 {
-    const size_t fo = (size_t)blockIdx.y * N;
-    const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool in = p < N;
-    const int m = in ? (int)mask[fo + p] : 0;
-    const int x = in ? p % W : 0;
-    const int mprev = __shfl_up(m, 1);
-    const bool start = m && (lane == 0 || x == 0 || mprev != m);
-    const unsigned long long sb = __ballot(start);
-    if (in) {
-        int par = -1;
-        if (m) {
-            unsigned long long below = sb & ((2ull << lane) - 1ull);   // starts at lanes <= lane
-            int s = 63 - __clzll(below);
-            par = p - (lane - s);
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_find(const int *L, int a)
+{
+    int p = lds_parent(L, a);
+    while (p != a) {
+        a = p;
+        p = lds_parent(L, a);
+    }
+    return a;
+}
+__device__ __forceinline__ void lds_union(int *L, int a, int b)
+{
+    bool done = false;
+    while (!done) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a < b) {
+            int old = atomicMin(L + b, a);
+            done = (old == b);
+            b = old;
+        } else if (b < a) {
+            int old = atomicMin(L + a, b);
+            done = (old == a);
+            a = old;
+        } else {
+            done = true;
         }
-        parent[fo + p] = par;
-        count[fo + p] = 0;
     }
 }
 
+// T = uint8_t (binary mask) or int32_t (label image): pixels are connected when their values are
+// equal and non-zero.
+// Every pixel of a tile ends up pointing at the first pixel (raster order) of its component within the
+// tile; the links across tile borders are left to cc_border_kernel.  Tile-local indices and flat frame
+// indices order the pixels of a tile the same way, so the smallest index stays the root in both.
 template <typename T>
-__global__ __launch_bounds__(CC_BLOCK) void cc_merge_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
-                                                            int N, int W)
+__global__ __launch_bounds__(LTW * LTH) void cc_local_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
+                                                             int32_t *__restrict__ count, int H, int W)
 {
-    const size_t fo = (size_t)blockIdx.y * N;
-    const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
-    if (p >= N) return;
+    __shared__ int lab[LTW * LTH];
+    __shared__ int val[LTW * LTH];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * LTW, y0 = blockIdx.y * LTH;
+    const int x = x0 + lane, y = y0 + ty;
+    const bool in = x < W && y < H;
+    const int m = in ? (int)mask[fo + (size_t)y * W + x] : 0;
+    const int l = ty * LTW + lane;
+    // row runs by ballot: a lane's parent is the start of its horizontal run
+    const int mprev = __shfl_up(m, 1);
+    const bool start = m && (lane == 0 || mprev != m);
+    const unsigned long long sb = __ballot(start);
+    int par = -1;
+    if (m) {
+        const unsigned long long below = sb & ((2ull << lane) - 1ull);   // starts at lanes <= lane
+        par = ty * LTW + (63 - __clzll(below));
+    }
+    lab[l] = par;
+    val[l] = m;
+    __syncthreads();
+    if (m && ty > 0 && val[l - LTW] == m) {
+        const bool covered = lane > 0 && val[l - 1] == m && val[l - LTW - 1] == m;   // the left pixel makes the same link
+        if (!covered) lds_union(lab, l, l - LTW);
+    }
+    __syncthreads();
+    if (in) {
+        int root = -1;
+        if (m) {
+            const int rl = lds_find(lab, l);
+            root = (y0 + rl / LTW) * W + x0 + (rl & (LTW - 1));
+        }
+        parent[fo + (size_t)y * W + x] = root;
+        count[fo + (size_t)y * W + x] = 0;
+    }
+}
+
+// Links across the tile borders of cc_local_kernel: lock-free union-find with atomicMin on the flat
+// indices (the root of a tree is always its smallest index, i.e. the component's first pixel in raster
+// order).  One lane per pixel of a tile's top row (link to the pixel above) or left column (link to the
+// pixel on the left); a link is skipped when the neighbouring border pixel of the same tile already makes it.
+template <typename T>
+__global__ __launch_bounds__(256) void cc_border_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent, int H, int W)
+{
+    const int rows = (H - 1) / LTH, cols = (W - 1) / LTW;       // tile borders inside the frame
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const size_t fo = (size_t)blockIdx.y * H * W;
     const T *M = mask + fo;
     int32_t *L = parent + fo;
-    const T m = M[p];
-    if (!m) return;
-    const int x = p % W;
-    const bool left = x > 0 && M[p - 1] == m;
-    if (left && (threadIdx.x & 63) == 0) uf_union(L, p, p - 1);   // run continues across the wave boundary
-    if (p >= W && M[p - W] == m) {
-        const bool covered = left && M[p - W - 1] == m;            // the left pixel makes the same vertical link
-        if (!covered) uf_union(L, p, p - W);
+    if (t < rows * W) {
+        const int y = (t / W + 1) * LTH, x = t % W, p = y * W + x;
+        const T m = M[p];
+        if (m && M[p - W] == m) {
+            const bool covered = (x % LTW) != 0 && M[p - 1] == m && M[p - W - 1] == m;
+            if (!covered) uf_union(L, p, p - W);
+        }
+    } else if (t < rows * W + cols * H) {
+        const int u = t - rows * W;
+        const int x = (u / H + 1) * LTW, y = u % H, p = y * W + x;
+        const T m = M[p];
+        if (m && M[p - 1] == m) {
+            const bool covered = (y % LTH) != 0 && M[p - W] == m && M[p - W - 1] == m;
+            if (!covered) uf_union(L, p, p - 1);
+        }
     }
 }
 
@@ -225,6 +291,16 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_relabel_kernel(const int32_t *__r
 
 }  // namespace
 
+template <typename T>
+static void launch_local_and_border(const T *mask, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(cc_local_kernel<T>, dim3((W + LTW - 1) / LTW, (H + LTH - 1) / LTH, n), dim3(LTW * LTH), 0, st, mask, parent,
+                       count, H, W);
+    const int links = ((H - 1) / LTH) * W + ((W - 1) / LTW) * H;
+    if (links > 0)
+        hipLaunchKernelGGL(cc_border_kernel<T>, dim3((links + 255) / 256, n), dim3(256), 0, st, mask, parent, H, W);
+}
+
 size_t cc_blocks_per_image(int H, int W) { return ((size_t)H * W + CC_BLOCK - 1) / CC_BLOCK; }
 
 void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_size_exclusive, int64_t *labels64,
@@ -233,8 +309,7 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const int N = H * W;
     const int nblk = (int)cc_blocks_per_image(H, W);
     const dim3 grid(nblk, n), block(CC_BLOCK);
-    hipLaunchKernelGGL(cc_init_kernel<uint8_t>, grid, block, 0, st, mask, w.parent, w.count, N, W);
-    hipLaunchKernelGGL(cc_merge_kernel<uint8_t>, grid, block, 0, st, mask, w.parent, N, W);
+    launch_local_and_border(mask, w.parent, w.count, n, H, W, st);
     hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, w.parent, w.count, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
@@ -246,8 +321,7 @@ void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *co
 {
     const int N = H * W;
     const dim3 grid((unsigned)cc_blocks_per_image(H, W), n), block(CC_BLOCK);
-    hipLaunchKernelGGL(cc_init_kernel<int32_t>, grid, block, 0, st, labels, parent, count, N, W);
-    hipLaunchKernelGGL(cc_merge_kernel<int32_t>, grid, block, 0, st, labels, parent, N, W);
+    launch_local_and_border(labels, parent, count, n, H, W, st);
     hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, parent, count, N);
 }
 
