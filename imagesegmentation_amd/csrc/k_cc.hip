@@ -15,8 +15,9 @@
 //              indices in global memory;
 //              the root of a tree is always its smallest flat index, i.e. the
 //              component's first pixel in raster order;
-//   3. flatten every pixel points at its root; per-root pixel counts with one
-//              atomicAdd per distinct root per wave;
+//   3. sizes   every tile-local root points at its component's root and adds the size
+//              of its tile-local component to the root's count (the other pixels stay
+//              two steps from the root);
 //   4. rank    surviving roots (count > threshold) are numbered by an exclusive
 //              prefix count in raster order (block sums -> scan -> in-block
 //              ballot/popcount), which is exactly the id the second
@@ -108,9 +109,12 @@ __device__ __forceinline__ void lds_union(int *L, int a, int b)
 // Every pixel of a tile ends up pointing at the first pixel (raster order) of its component within the
 // tile; the links across tile borders are left to cc_border_kernel.  Tile-local indices and flat frame
 // indices order the pixels of a tile the same way, so the smallest index stays the root in both.
-template <typename T>
+// SIZES: lsize receives the size of the tile-local component at its root and 0 elsewhere, and only the roots'
+// counts are zeroed (cc_sum_sizes_kernel then works on the local roots only); otherwise every pixel's count is
+// zeroed for cc_flatten_count_kernel.
+template <typename T, bool SIZES>
 __global__ __launch_bounds__(LTW * LTH) void cc_local_kernel(const T *__restrict__ mask, int32_t *__restrict__ parent,
-                                                             int32_t *__restrict__ count, int H, int W)
+                                                             int32_t *__restrict__ count, int32_t *__restrict__ lsize, int H, int W)
 {
     __shared__ int lab[LTW * LTH];
     __shared__ int val[LTW * LTH];
@@ -138,14 +142,27 @@ __global__ __launch_bounds__(LTW * LTH) void cc_local_kernel(const T *__restrict
         if (!covered) lds_union(lab, l, l - LTW);
     }
     __syncthreads();
+    const int rl = m ? lds_find(lab, l) : -1;
     if (in) {
-        int root = -1;
-        if (m) {
-            const int rl = lds_find(lab, l);
-            root = (y0 + rl / LTW) * W + x0 + (rl & (LTW - 1));
+        parent[fo + (size_t)y * W + x] = m ? (y0 + rl / LTW) * W + x0 + (rl & (LTW - 1)) : -1;
+        if (!SIZES) count[fo + (size_t)y * W + x] = 0;
+    }
+    if (SIZES) {
+        // sizes of the tile-local components: one LDS add per distinct root of a wave (a row holds few)
+        __syncthreads();
+        val[l] = 0;
+        __syncthreads();
+        unsigned long long todo = __ballot(rl >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int r = __shfl(rl, leader);
+            const unsigned long long same = __ballot(rl == r) & todo;
+            if (lane == leader) atomicAdd(val + r, __popcll(same));
+            todo &= ~same;
         }
-        parent[fo + (size_t)y * W + x] = root;
-        count[fo + (size_t)y * W + x] = 0;
+        __syncthreads();
+        if (in) lsize[fo + (size_t)y * W + x] = rl == l ? val[l] : 0;      // > 0 marks a tile-local root
+        if (rl == l) count[fo + (size_t)y * W + x] = 0;
     }
 }
 
@@ -177,6 +194,25 @@ __global__ __launch_bounds__(256) void cc_border_kernel(const T *__restrict__ ma
             if (!covered) uf_union(L, p, p - 1);
         }
     }
+}
+
+// After the border links: every tile-local root looks up its component's root, points at it directly and adds
+// its local size to the root's count.  The other pixels keep pointing at their local root, which is one step
+// from the root afterwards (cc_relabel_kernel takes the two steps).
+__global__ __launch_bounds__(CC_BLOCK) void cc_sum_sizes_kernel(int32_t *__restrict__ parent, int32_t *__restrict__ count,
+                                                                const int32_t *__restrict__ lsize, int N)
+{
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
+    if (p >= N) return;
+    const int ls = lsize[fo + p];
+    if (ls <= 0) return;
+    // only roots were changed by the border links (to smaller indices), so the way up leads over former roots
+    int a = p;
+    int q = ld_parent(parent + fo, a);
+    while (q != a) { a = q; q = ld_parent(parent + fo, a); }
+    if (a != p) parent[fo + p] = a;
+    atomicAdd(count + fo + a, ls);
 }
 
 __global__ __launch_bounds__(CC_BLOCK) void cc_flatten_count_kernel(int32_t *__restrict__ parent, int32_t *__restrict__ count, int N)
@@ -283,7 +319,8 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_relabel_kernel(const int32_t *__r
     const size_t fo = (size_t)blockIdx.y * N;
     const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
     if (p >= N) return;
-    const int root = parent[fo + p];
+    int root = parent[fo + p];                          // tile-local root, itself one step from the root
+    if (root >= 0) root = parent[fo + root];
     const int id = root >= 0 ? newid[fo + root] : 0;
     if (labels64) labels64[fo + p] = id;
     if (labels32) labels32[fo + p] = id;
@@ -291,11 +328,11 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_relabel_kernel(const int32_t *__r
 
 }  // namespace
 
-template <typename T>
-static void launch_local_and_border(const T *mask, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st)
+template <typename T, bool SIZES>
+static void launch_local_and_border(const T *mask, int32_t *parent, int32_t *count, int32_t *lsize, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(cc_local_kernel<T>, dim3((W + LTW - 1) / LTW, (H + LTH - 1) / LTH, n), dim3(LTW * LTH), 0, st, mask, parent,
-                       count, H, W);
+    hipLaunchKernelGGL((cc_local_kernel<T, SIZES>), dim3((W + LTW - 1) / LTW, (H + LTH - 1) / LTH, n), dim3(LTW * LTH), 0, st, mask, parent,
+                       count, lsize, H, W);
     const int links = ((H - 1) / LTH) * W + ((W - 1) / LTW) * H;
     if (links > 0)
         hipLaunchKernelGGL(cc_border_kernel<T>, dim3((links + 255) / 256, n), dim3(256), 0, st, mask, parent, H, W);
@@ -309,8 +346,8 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const int N = H * W;
     const int nblk = (int)cc_blocks_per_image(H, W);
     const dim3 grid(nblk, n), block(CC_BLOCK);
-    launch_local_and_border(mask, w.parent, w.count, n, H, W, st);
-    hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, w.parent, w.count, N);
+    launch_local_and_border<uint8_t, true>(mask, w.parent, w.count, w.newid, n, H, W, st);   // newid holds the local sizes until cc_rank
+    hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
     hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
@@ -321,7 +358,7 @@ void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *co
 {
     const int N = H * W;
     const dim3 grid((unsigned)cc_blocks_per_image(H, W), n), block(CC_BLOCK);
-    launch_local_and_border(labels, parent, count, n, H, W, st);
+    launch_local_and_border<int32_t, false>(labels, parent, count, nullptr, n, H, W, st);
     hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, parent, count, N);
 }
 
