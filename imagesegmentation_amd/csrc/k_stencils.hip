@@ -49,17 +49,42 @@ __global__ __launch_bounds__(NT) void smooth_depth_kernel(const T *__restrict__ 
     __syncthreads();
     const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
     const int x = x0 + tx, y = y0 + ty;
-    if (x >= W || y >= H) return;
     float sums = 0.0f, val = 0.0f;
+    if (sizeof(T) == 2) {
+        // 16-bit depths: the sums are integers below 2^24, exact in fp32 in any order, so the window is
+        // summed along rows first (once per row and column of the tile) and then along columns
+        __shared__ float hsum[TH + 2 * R][TW], hcnt[TH + 2 * R][TW];
+        for (int i = threadIdx.x; i < (TH + 2 * R) * TW; i += NT) {
+            const int ly = i / TW, lx = i - ly * TW;
+            float s = 0.0f, c = 0.0f;
 #pragma unroll
-    for (int wy = 0; wy <= 2 * R; ++wy)
-#pragma unroll
-        for (int wx = 0; wx <= 2 * R; ++wx) {
-            float d = tile[ty + wy][tx + wx];
-            float ind = d < 0.001f ? 0.0f : 1.0f;
-            sums = sums + ind;
-            val = val + ind * d;
+            for (int wx = 0; wx <= 2 * R; ++wx) {
+                const float d = tile[ly][lx + wx];
+                s = s + d;                                  // an invalid depth is 0
+                c = c + (d < 0.001f ? 0.0f : 1.0f);
+            }
+            hsum[ly][lx] = s;
+            hcnt[ly][lx] = c;
         }
+        __syncthreads();
+        if (x >= W || y >= H) return;
+#pragma unroll
+        for (int wy = 0; wy <= 2 * R; ++wy) {
+            sums = sums + hcnt[ty + wy][tx];
+            val = val + hsum[ty + wy][tx];
+        }
+    } else {
+        if (x >= W || y >= H) return;
+#pragma unroll
+        for (int wy = 0; wy <= 2 * R; ++wy)
+#pragma unroll
+            for (int wx = 0; wx <= 2 * R; ++wx) {
+                float d = tile[ty + wy][tx + wx];
+                float ind = d < 0.001f ? 0.0f : 1.0f;
+                sums = sums + ind;
+                val = val + ind * d;
+            }
+    }
     float c = tile[ty + R][tx + R];
     out[fo + (size_t)y * W + x] = div_no_nan(val, sums) * (c < 0.001f ? 0.0f : 1.0f);
 }
