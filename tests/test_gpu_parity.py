@@ -87,6 +87,39 @@ def test_connected_components_size_filter(small_ctx, oracle):
         assert cnt[i] == n_o and np.array_equal(lab[i], l_o)
 
 
+def test_connected_components_structured_and_ragged_frame(oracle):
+    """Components that wind through many 64 x 16 tiles, on a frame whose sides are not multiples of the tile:
+    a spiral, a comb, concentric rings, a checkerboard (no 4-connections at all), a full frame and thin
+    diagonals; with and without the size filter."""
+    from imagesegmentation_amd._lib import Context
+    H, W = 100, 150
+    yy, xx = np.mgrid[0:H, 0:W]
+    spiral = np.zeros((H, W), np.uint8)
+    t, l, b, r = 0, 0, H - 1, W - 1
+    while t <= b and l <= r:                      # one-pixel wall spiralling inwards with one-pixel gaps
+        spiral[t, l:r + 1] = 1
+        spiral[t:b + 1, r] = 1
+        if t + 2 <= b:
+            spiral[b, l + 2:r + 1] = 1
+            spiral[t + 2:b + 1, l + 2] = 1
+        t, l, b, r = t + 2, l + 2, b - 2, r - 2
+    comb = ((xx % 4 == 0) | (yy == H - 1)).astype(np.uint8)
+    rings = ((np.maximum(np.abs(yy - H // 2), np.abs(xx - W // 2)) % 3) == 0).astype(np.uint8)
+    checker = ((yy + xx) % 2).astype(np.uint8)
+    full = np.ones((H, W), np.uint8)
+    stairs = (((yy - xx) % 7 == 0) | ((yy - xx) % 7 == 1)).astype(np.uint8)
+    masks = np.stack([spiral, comb, rings, checker, full, stairs])
+    with Context(H, W, max_batch=len(masks)) as ctx:
+        for thr in (0, 20):
+            lab, cnt = ctx.connected_components(masks, thr)
+            for i, m in enumerate(masks):
+                l0, _ = oracle.connected_components(m.astype(np.int32))
+                keep = (np.bincount(l0.ravel()) > thr)[l0] & (m != 0)
+                l_o, n_o = oracle.connected_components(keep.astype(np.int32))
+                assert cnt[i] == n_o, (i, thr, cnt[i], n_o)
+                assert np.array_equal(lab[i], l_o), (i, thr)
+
+
 def _crf_inputs(oracle, seed, H, W, r=7):
     d, c = _scenes([seed], H, W)
     d, c = d[0], c[0]
