@@ -40,6 +40,7 @@
 // first read of the lane that owns p-o at the same step, so within a tile both
 // uses of a similarity value reach L2/HBM once.
 #include <cmath>
+#include <cstdlib>
 
 #include "fs_common.h"
 #ifndef FS_SKIPQ
@@ -1141,7 +1142,14 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (!ok[i] || FS_SKIPFIN) continue;
+        if (FS_SKIPFIN) {                          // timing experiments: keep the messages alive without the epilogue
+            float t = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH * CH; ++c) t += acc[c / CH][i][c % CH];
+            if (t == 12345.678f) d.depth_raw ? (void)(const_cast<float *>(d.Qin)[0] = t) : (void)0;
+            continue;
+        }
+        if (!ok[i]) continue;
         float m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][i][c % CH];
@@ -1206,7 +1214,12 @@ hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom 
     hipError_t qe = hipMemsetAsync(queue, 0, kCrfQueueBytes, st);
     if (qe != hipSuccess) return qe;
     const unsigned nblk = (tiles + 7u) / 8u * 8u;
-    dim3 grid(nblk < 512u ? nblk : 512u);
+    static const unsigned max_blocks = [] {                  // FS_CRF_BLOCKS: experiments with fewer or more resident blocks
+        const char *e = getenv("FS_CRF_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 8 ? (unsigned)v / 8u * 8u : 512u;
+    }();
+    dim3 grid(nblk < max_blocks ? nblk : max_blocks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, descs, g, K, wtab, weight, first, last, nframes, queue);
     return hipGetLastError();
 }
