@@ -154,16 +154,28 @@ __global__ __launch_bounds__(NT) void normals_kernel(const float *__restrict__ D
 // uniform_filter_with_depth_cutoff + Depth_Cutoff
 // (image_processing_models_GPU.py:102-108, 86-88).
 // ---------------------------------------------------------------------------
+constexpr int ATH = 16;   // tile height of the angle filter: 256 lanes x 2 vertically adjacent pixels
+
+// one tap of one pixel's window: product test, band flag, the three running sums
+#define FS_ANGLE_TAP(Q, LO, HI, BAND, SUMS, V0, V1)        \
+    {                                                      \
+        const float m_ = (Q) > (HI) ? 0.0f : 1.0f;         \
+        BAND |= (Q) >= (LO) && (Q) <= (HI);                \
+        SUMS = SUMS + m_;                                  \
+        V0 = V0 + m_ * a0;                                 \
+        V1 = V1 + m_ * a1;                                 \
+    }
+
 __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restrict__ raw, const float *__restrict__ D,
                                                           float *__restrict__ angles, int H, int W)
 {
     constexpr int R = 3;
-    constexpr int LW = TW + 2 * R, LH = TH + 2 * R;
+    constexpr int LW = TW + 2 * R, LH = ATH + 2 * R;
     __shared__ float td[LH][LW + 1];
     __shared__ float ta0[LH][LW + 1];
     __shared__ float ta1[LH][LW + 1];
     const size_t fo = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * ATH;
     for (int i = threadIdx.x; i < LW * LH; i += NT) {
         int ly = i / LW, lx = i - ly * LW;
         int y = y0 + ly - R, x = x0 + lx - R;
@@ -180,46 +192,62 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
         ta1[ly][lx] = a1;
     }
     __syncthreads();
-    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    // A lane owns the pixels (ty, tx) and (ty + 1, tx): their windows share six of seven rows, so the eight
+    // rows are read once and each tap feeds the pixel(s) whose window holds it.  Every pixel still adds its
+    // 49 taps in window order (rows top to bottom, left to right), which fixes the rounding of its sums.
+    const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * 2;
     const int x = x0 + tx, y = y0 + ty;
     if (x >= W || y >= H) return;
-    const float dc = td[ty + R][tx + R];
     // Weight of a tap: m = |divide_no_nan(dj - dc, dc)| > 0.3 ? 0 : 1.  The rounded quotient differs
     // from the exact one by less than one part in 1e7, so comparing |dj - dc| with 0.3 |dc| decides
     // except in a band of that width around the threshold.  The window is summed with the product
     // test; a pixel that met the band (about one tap in 1e6) is summed again with the division.
     // dc == 0: divide_no_nan gives 0 and every weight is 1 (thresholds +inf).
-    const float lo = dc == 0.0f ? INFINITY : 0.3f * fabsf(dc) * (1.0f - 4e-7f);
-    const float hi = dc == 0.0f ? INFINITY : 0.3f * fabsf(dc) * (1.0f + 4e-7f);
-    float sums = 0.0f, v0 = 0.0f, v1 = 0.0f;
-    bool band = false;
-#pragma unroll
-    for (int wy = 0; wy <= 2 * R; ++wy)
+    const float dcA = td[ty + R][tx + R], dcB = td[ty + 1 + R][tx + R];
+    const float loA = dcA == 0.0f ? INFINITY : 0.3f * fabsf(dcA) * (1.0f - 4e-7f);
+    const float hiA = dcA == 0.0f ? INFINITY : 0.3f * fabsf(dcA) * (1.0f + 4e-7f);
+    const float loB = dcB == 0.0f ? INFINITY : 0.3f * fabsf(dcB) * (1.0f - 4e-7f);
+    const float hiB = dcB == 0.0f ? INFINITY : 0.3f * fabsf(dcB) * (1.0f + 4e-7f);
+    float sumsA = 0.0f, v0A = 0.0f, v1A = 0.0f, sumsB = 0.0f, v0B = 0.0f, v1B = 0.0f;
+    bool bandA = false, bandB = false;
+    // one region row: the taps go to the upper pixel (A), the lower one (B) or both.  The rows stay a loop
+    // (fully unrolled, the compiler reads all 168 values first and the registers cost the occupancy).
+    auto row = [&](int wy, bool toA, bool toB) {
 #pragma unroll
         for (int wx = 0; wx <= 2 * R; ++wx) {
-            const float q = fabsf(td[ty + wy][tx + wx] - dc);
-            const float m = q > hi ? 0.0f : 1.0f;
-            band |= q >= lo && q <= hi;
-            sums = sums + m;
-            v0 = v0 + m * ta0[ty + wy][tx + wx];
-            v1 = v1 + m * ta1[ty + wy][tx + wx];
+            const float dj = td[ty + wy][tx + wx], a0 = ta0[ty + wy][tx + wx], a1 = ta1[ty + wy][tx + wx];
+            if (toA) {
+                const float q = fabsf(dj - dcA);
+                FS_ANGLE_TAP(q, loA, hiA, bandA, sumsA, v0A, v1A)
+            }
+            if (toB) {
+                const float q = fabsf(dj - dcB);
+                FS_ANGLE_TAP(q, loB, hiB, bandB, sumsB, v0B, v1B)
+            }
         }
-    if (band) {
+    };
+    row(0, true, false);
+#pragma unroll 1
+    for (int wy = 1; wy <= 2 * R; ++wy) row(wy, true, true);
+    row(2 * R + 1, false, true);
+    auto exact = [&](int oy, float dc, float &sums, float &v0, float &v1) {
         sums = 0.0f; v0 = 0.0f; v1 = 0.0f;
         for (int wy = 0; wy <= 2 * R; ++wy)
             for (int wx = 0; wx <= 2 * R; ++wx) {
-                const float dj = td[ty + wy][tx + wx];
+                const float dj = td[ty + oy + wy][tx + wx];
                 const float m = fabsf(div_no_nan(dj - dc, dc)) > 0.3f ? 0.0f : 1.0f;
                 sums = sums + m;
-                v0 = v0 + m * ta0[ty + wy][tx + wx];
-                v1 = v1 + m * ta1[ty + wy][tx + wx];
+                v0 = v0 + m * ta0[ty + oy + wy][tx + wx];
+                v1 = v1 + m * ta1[ty + oy + wy][tx + wx];
             }
-    }
-    float2 o;
-    o.x = div_no_nan(v0, sums);
-    o.y = div_no_nan(v1, sums);
-    reinterpret_cast<float2 *>(angles)[fo + (size_t)y * W + x] = o;
+    };
+    if (bandA) exact(0, dcA, sumsA, v0A, v1A);
+    if (bandB) exact(1, dcB, sumsB, v0B, v1B);
+    float2 *out = reinterpret_cast<float2 *>(angles) + fo + (size_t)y * W + x;
+    out[0] = make_float2(div_no_nan(v0A, sumsA), div_no_nan(v1A, sumsA));
+    if (y + 1 < H) out[W] = make_float2(div_no_nan(v0B, sumsB), div_no_nan(v1B, sumsB));
 }
+#undef FS_ANGLE_TAP
 
 // ---------------------------------------------------------------------------
 // Curvature score + threshold (find_surfaces.py:232-262, depth = 4).
@@ -438,7 +466,7 @@ void launch_normals(const float *D, const float *tanx, const float *tany, float 
 }
 void launch_angle_filter(const float *raw_angles, const float *D, float *angles, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(angle_filter_kernel, tile_grid(n, H, W), dim3(NT), 0, st, raw_angles, D, angles, H, W);
+    hipLaunchKernelGGL(angle_filter_kernel, dim3((W + TW - 1) / TW, (H + ATH - 1) / ATH, n), dim3(NT), 0, st, raw_angles, D, angles, H, W);
 }
 void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
                            float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st)
