@@ -115,6 +115,20 @@ __global__ __launch_bounds__(NT) void normals_kernel(const float *__restrict__ D
     const float du = tile[ty][tx + 1], dd = tile[ty + 2][tx + 1], dl = tile[ty + 1][tx], dr = tile[ty + 1][tx + 2];
     const float tyu = y > 0 ? tany[y - 1] : 0.0f, tyd = y < H - 1 ? tany[y + 1] : 0.0f;
     const float txl = x > 0 ? tanx[x - 1] : 0.0f, txr = x < W - 1 ? tanx[x + 1] : 0.0f;
+    const size_t i = fo + (size_t)y * W + x;
+    if (du == 0.0f && dd == 0.0f && dl == 0.0f && dr == 0.0f) {
+        // no depth around the pixel (a quarter of a sensor frame, in blobs): both differences are the zero
+        // vector, and the formulas below give a zero normal (divide_no_nan) and zero angles (acos(0) * sign(0))
+        points[3 * i + 0] = txc * dc;
+        points[3 * i + 1] = tyc * dc;
+        points[3 * i + 2] = dc;
+        normals[3 * i + 0] = 0.0f;
+        normals[3 * i + 1] = 0.0f;
+        normals[3 * i + 2] = 0.0f;
+        raw_angles[2 * i + 0] = 0.0f;
+        raw_angles[2 * i + 1] = 0.0f;
+        return;
+    }
     float a[3], b[3], v[3];
     a[0] = txc * du - txc * dd;   // sub_1 = P[y-1] - P[y+1]
     a[1] = tyu * du - tyd * dd;
@@ -138,7 +152,6 @@ __global__ __launch_bounds__(NT) void normals_kernel(const float *__restrict__ D
     const float n2 = sqrtf((v2[0] * v2[0] + v2[1] * v2[1]) + v2[2] * v2[2]);
     const float a1 = acosf(fminf(fmaxf(div_no_nan(-v1[2], n1), -1.0f), 1.0f)) * signf(v1[1]);
     const float a2 = acosf(fminf(fmaxf(div_no_nan(-v2[2], n2), -1.0f), 1.0f)) * (-signf(v2[0]));
-    const size_t i = fo + (size_t)y * W + x;
     points[3 * i + 0] = txc * dc;
     points[3 * i + 1] = tyc * dc;
     points[3 * i + 2] = dc;
