@@ -43,6 +43,9 @@
 #include <cstdlib>
 
 #include "fs_common.h"
+// Timing experiments only (never defined in the product build): -DFS_SKIPMAIN=1 drops the window walk of the
+// fused update, -DFS_SKIPQ=1 the staging of Q, -DFS_SKIPFIN=1 the epilogue.  Builds with parts switched off,
+// run under the SQ counters (tools/pmc_variant.sh), tell how the vector instructions split over the phases.
 #ifndef FS_SKIPQ
 #define FS_SKIPQ 0
 #endif
