@@ -406,21 +406,32 @@ __global__ __launch_bounds__(256) void curvature_exact_kernel(const float *__res
 // LDS for the tile plus a one-pixel ring (zero outside the frame, as the second
 // extract_patches pads it).
 // ---------------------------------------------------------------------------
+constexpr int MTH = 32;   // tile height of the majority / edge kernel: 256 lanes x 4 rows (fewer, fatter blocks:
+                          // the kernel is a chain of load and barrier latencies, not bandwidth)
+
 __global__ __launch_bounds__(NT) void majority_edges_kernel(const uint8_t *__restrict__ curv, const float *__restrict__ D,
                                                             const float *__restrict__ ax, const float *__restrict__ ay,
                                                             float alpha, uint8_t *__restrict__ mask,
                                                             int32_t *__restrict__ edges, int H, int W)
 {
     constexpr int R = 3;
-    __shared__ float tm[TH + 2 * R][TW + 2 * R + 1];
-    __shared__ float td[TH + 2][TW + 2 + 1];
-    __shared__ int m5[TH + 2][TW + 2 + 1];
+    __shared__ float tm[MTH + 2 * R][TW + 2 * R + 1];
+    __shared__ float td[MTH + 2][TW + 2 + 1];
+    __shared__ int m5[MTH + 2][TW + 2 + 1];
     const size_t fo = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    load_tile<R>(tm, curv + fo, H, W, x0, y0);
-    load_tile<1>(td, D + fo, H, W, x0, y0);
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * MTH;
+    for (int i = threadIdx.x; i < (MTH + 2 * R) * (TW + 2 * R); i += NT) {
+        const int ly = i / (TW + 2 * R), lx = i - ly * (TW + 2 * R);
+        const int y = y0 + ly - R, x = x0 + lx - R;
+        tm[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? (float)curv[fo + (size_t)y * W + x] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < (MTH + 2) * (TW + 2); i += NT) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        td[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? D[fo + (size_t)y * W + x] : 0.0f;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += NT) {
+    for (int i = threadIdx.x; i < (MTH + 2) * (TW + 2); i += NT) {
         int ly = i / (TW + 2), lx = i - ly * (TW + 2);
         int y = y0 + ly - 1, x = x0 + lx - 1;
         int v = 0;
@@ -435,29 +446,32 @@ __global__ __launch_bounds__(NT) void majority_edges_kernel(const uint8_t *__res
         m5[ly][lx] = v;
     }
     __syncthreads();
-    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
-    const int c = x0 + tx, r = y0 + ty;
-    if (c >= W || r >= H) return;
-    int s3 = 0;
+    const int tx = threadIdx.x % TW, c = x0 + tx;
+    if (c >= W) return;
+    for (int ty = threadIdx.x / TW; ty < MTH; ty += NT / TW) {
+        const int r = y0 + ty;
+        if (r >= H) break;
+        int s3 = 0;
 #pragma unroll
-    for (int wy = 0; wy < 3; ++wy)
+        for (int wy = 0; wy < 3; ++wy)
 #pragma unroll
-        for (int wx = 0; wx < 3; ++wx) s3 += m5[ty + wy][tx + wx];
-    const int pix = s3 > 5 ? 1 : 0;
-    int e = 0;
-    if (r >= 1 && r < H - 1 && c >= 1 && c < W - 1) {
-        const float dc = td[ty + 1][tx + 1];
-        const float fx = ((ax[c] * dc) * 0.5f) * alpha;
-        const float fy = ((ay[r] * dc) * 0.5f) * alpha;
-        e = 1;
-        if (fabsf(td[ty + 1][tx + 2] - dc) > fx) e = 0;
-        if (fabsf(td[ty + 1][tx] - dc) > fx) e = 0;
-        if (fabsf(td[ty][tx + 1] - dc) > fy) e = 0;
-        if (fabsf(td[ty + 2][tx + 1] - dc) > fy) e = 0;
+            for (int wx = 0; wx < 3; ++wx) s3 += m5[ty + wy][tx + wx];
+        const int pix = s3 > 5 ? 1 : 0;
+        int e = 0;
+        if (r >= 1 && r < H - 1 && c >= 1 && c < W - 1) {
+            const float dc = td[ty + 1][tx + 1];
+            const float fx = ((ax[c] * dc) * 0.5f) * alpha;
+            const float fy = ((ay[r] * dc) * 0.5f) * alpha;
+            e = 1;
+            if (fabsf(td[ty + 1][tx + 2] - dc) > fx) e = 0;
+            if (fabsf(td[ty + 1][tx] - dc) > fx) e = 0;
+            if (fabsf(td[ty][tx + 1] - dc) > fy) e = 0;
+            if (fabsf(td[ty + 2][tx + 1] - dc) > fy) e = 0;
+        }
+        const size_t i = fo + (size_t)r * W + c;
+        edges[i] = e;
+        mask[i] = (uint8_t)(e * pix);
     }
-    const size_t i = fo + (size_t)r * W + c;
-    edges[i] = e;
-    mask[i] = (uint8_t)(e * pix);
 }
 
 inline dim3 tile_grid(int n, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, n); }
@@ -497,7 +511,7 @@ size_t curvature_todo_ints(int n, int todo_cap) { return (size_t)n * (1 + (size_
 void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
                            uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(majority_edges_kernel, tile_grid(n, H, W), dim3(NT), 0, st, curv, D, ax, ay, alpha, mask, edges, H, W);
+    hipLaunchKernelGGL(majority_edges_kernel, dim3((W + TW - 1) / TW, (H + MTH - 1) / MTH, n), dim3(NT), 0, st, curv, D, ax, ay, alpha, mask, edges, H, W);
 }
 
 }  // namespace fs
