@@ -41,6 +41,7 @@ SIGNATURES = {
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
+    "fs_surface_stats_dev": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
     "fs_chi_squared_distances": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "fs_nearest_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -337,6 +338,21 @@ class Context:
         self._check(self._lib.fs_surface_stats(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
                                                _ptr(angles), _ptr(lab), _ptr(texture), T, *(_ptr(out[k]) for k in order)))
         return out
+
+    STATS_OUTPUTS = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+                     "hist_color", "hist_angle", "hist_texture", "avg_angles", "neighbor_counts", "border_centers", "norm",
+                     "depth_extend")
+
+    def surface_stats_dev(self, num_surfaces, d_surfaces, d_patches, d_depth_edges, d_points_3d, d_angles, d_lab,
+                          d_texture=None, texture_dim=256, **d_out):
+        """fs_surface_stats_dev: device pointers (integers); outputs by the names of STATS_OUTPUTS, missing ones
+        are not produced.  Sizes as in surface_stats()."""
+        unknown = set(d_out) - set(self.STATS_OUTPUTS)
+        if unknown:
+            raise TypeError(f"unknown outputs {sorted(unknown)}")
+        self._check(self._lib.fs_surface_stats_dev(self._h, int(num_surfaces), d_surfaces, d_patches, d_depth_edges, d_points_3d,
+                                                   d_angles, d_lab, d_texture, int(texture_dim),
+                                                   *(d_out.get(k) for k in self.STATS_OUTPUTS)))
 
     def chi_squared_distances(self, hist, pool_size=(1, 1), strides=(1, 1)):
         hist = _arr(hist, np.float64)

@@ -858,6 +858,88 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     return 0;
 }
 
+namespace {
+
+constexpr int kStatsOutputs = 15;
+
+// Shared body of fs_surface_stats and fs_surface_stats_dev.  `in` and the non-null entries of user_out are device
+// pointers; outputs the caller did not ask for go to the context's staging buffer.  od[i] receives the device address
+// output i was written to, out_sizes[i] its size in bytes.  Synchronises once to read the error flag.
+int surface_stats_core(fs_ctx *ctx, const char *who, int S, int T, const StatsIn &in, void *const user_out[kStatsOutputs],
+                       char *od[kStatsOutputs], size_t out_sizes[kStatsOutputs])
+{
+    const int H = ctx->H, W = ctx->W;
+    const size_t N = ctx->N();
+    auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
+    FS_HIP(ctx->st_work.ensure(8 * up8(N * 4)));
+    StatsWork w{};
+    {
+        char *p = ctx->st_work.as<char>();
+        void **slots[8] = {(void **)&w.surf32, (void **)&w.pat32, (void **)&w.parent, (void **)&w.count,
+                           (void **)&w.sort_key, (void **)&w.sort_key_out, (void **)&w.sort_val, (void **)&w.sort_val_out};
+        for (auto *sl : slots) { *sl = p; p += up8(N * 4); }
+    }
+    w.sort_temp_bytes = stats_sort_temp_bytes((int)N);
+    FS_HIP(ctx->st_sort.ensure(w.sort_temp_bytes));
+    w.sort_temp = ctx->st_sort.p;
+    FS_HIP(ctx->st_scratch.ensure(stats_work_bytes(S, T) + 256));
+    w.scratch = ctx->st_scratch.p;
+    const size_t SS = (size_t)S * S;
+    const size_t sizes[kStatsOutputs] = {N * 8, (size_t)(S + 1) * 4, N * 8, (size_t)S * 16, (size_t)S * 8, (size_t)S * 12, (size_t)S * 8,
+                                         (size_t)65536 * S * 8, (size_t)1600 * S * 8, (size_t)S * T * 8, (size_t)S * 16, SS * 8, SS * 16,
+                                         N * 4, (size_t)S * 32};
+    size_t staged = 256;                                      // the error flag
+    for (int i = 0; i < kStatsOutputs; ++i) {
+        out_sizes[i] = sizes[i];
+        if (!user_out[i]) staged += up8(sizes[i]);
+    }
+    FS_HIP(ctx->st_out.ensure(staged));
+    char *p = ctx->st_out.as<char>();
+    int *d_err = reinterpret_cast<int *>(p);
+    p += 256;
+    for (int i = 0; i < kStatsOutputs; ++i) {
+        if (user_out[i]) od[i] = static_cast<char *>(user_out[i]);
+        else { od[i] = p; p += up8(sizes[i]); }
+    }
+    StatsOut out{};
+    out.surfaces = reinterpret_cast<int64_t *>(od[0]);
+    out.patch_point_offsets = reinterpret_cast<int32_t *>(od[1]);
+    out.patch_points = reinterpret_cast<float *>(od[2]);
+    out.avg_pos = reinterpret_cast<double *>(od[3]);
+    out.counts = reinterpret_cast<double *>(od[4]);
+    out.centroids = reinterpret_cast<float *>(od[5]);
+    out.centroid_idx = reinterpret_cast<int32_t *>(od[6]);
+    out.hist_color = reinterpret_cast<double *>(od[7]);
+    out.hist_angle = reinterpret_cast<double *>(od[8]);
+    out.hist_texture = reinterpret_cast<double *>(od[9]);
+    out.avg_angles = reinterpret_cast<double *>(od[10]);
+    out.neighbors = reinterpret_cast<double *>(od[11]);
+    out.border_centers = reinterpret_cast<double *>(od[12]);
+    out.norm = reinterpret_cast<float *>(od[13]);
+    out.depth_extend = reinterpret_cast<float *>(od[14]);
+    out.err = d_err;
+    hipError_t e = launch_surface_stats(in, w, out, H, W, S, T, ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, (std::string(who) + ": launch").c_str());
+    int err = 0;
+    FS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    if (err == 1) return ctx->fail(std::string(who) + ": a label lies outside [0, num_surfaces)");
+    if (err == 2) return ctx->fail(std::string(who) + ": Lab a/b + 127 rounds outside [0, 255]");
+    if (err == 3) return ctx->fail(std::string(who) + ": angle outside [-pi, pi]");
+    return 0;
+}
+
+int stats_check_args(fs_ctx *ctx, const char *who, int S, int T, bool has_texture, bool inputs_ok)
+{
+    if (S < 1 || S > kMaxLabels) return ctx->fail(std::string(who) + ": num_surfaces outside [1, " + std::to_string(kMaxLabels) + "]");
+    if (T < 1 || T > 4096) return ctx->fail(std::string(who) + ": texture_dim outside [1, 4096]");
+    if (has_texture && (ctx->H % 4 || ctx->W % 4)) return ctx->fail(std::string(who) + ": texture input needs frame sides divisible by 4");
+    if (!inputs_ok) return ctx->fail(std::string(who) + ": null input");
+    return 0;
+}
+
+}  // namespace
+
 int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, const int64_t *patches, const int32_t *depth_edges,
                      const float *points_3d, const float *angles, const double *lab, const float *texture, int texture_dim,
                      int64_t *surfaces_out, int32_t *patch_point_offsets, float *patch_points, double *avg_pos, double *counts,
@@ -866,14 +948,12 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
 {
     if (!ctx) return -1;
     if (set_device(ctx)) return -1;
-    const int S = num_surfaces, T = texture_dim, H = ctx->H, W = ctx->W;
-    if (S < 1 || S > kMaxLabels) return ctx->fail("fs_surface_stats: num_surfaces outside [1, " + std::to_string(kMaxLabels) + "]");
-    if (T < 1 || T > 4096) return ctx->fail("fs_surface_stats: texture_dim outside [1, 4096]");
-    if (texture && (H % 4 || W % 4)) return ctx->fail("fs_surface_stats: texture input needs frame sides divisible by 4");
-    if (!surfaces || !patches || !depth_edges || !points_3d || !angles || !lab) return ctx->fail("fs_surface_stats: null input");
+    const int S = num_surfaces, T = texture_dim;
+    if (stats_check_args(ctx, "fs_surface_stats", S, T, texture != nullptr,
+                         surfaces && patches && depth_edges && points_3d && angles && lab))
+        return -1;
     const size_t N = ctx->N();
     auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
-    // inputs
     const size_t in_sizes[7] = {N * 8, N * 8, N * 4, N * 12, N * 8, N * 24, texture ? N / 16 * T * 4 : 0};
     const void *in_host[7] = {surfaces, patches, depth_edges, points_3d, angles, lab, texture};
     size_t in_total = 0;
@@ -896,95 +976,45 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
     in.angles = reinterpret_cast<const float *>(in_dev[4]);
     in.lab = reinterpret_cast<const double *>(in_dev[5]);
     in.texture = texture ? reinterpret_cast<const float *>(in_dev[6]) : nullptr;
-    // work
-    FS_HIP(ctx->st_work.ensure(8 * up8(N * 4)));
-    StatsWork w{};
-    {
-        char *p = ctx->st_work.as<char>();
-        void **slots[8] = {(void **)&w.surf32, (void **)&w.pat32, (void **)&w.parent, (void **)&w.count,
-                           (void **)&w.sort_key, (void **)&w.sort_key_out, (void **)&w.sort_val, (void **)&w.sort_val_out};
-        for (auto *sl : slots) { *sl = p; p += up8(N * 4); }
-    }
-    w.sort_temp_bytes = stats_sort_temp_bytes((int)N);
-    FS_HIP(ctx->st_sort.ensure(w.sort_temp_bytes));
-    w.sort_temp = ctx->st_sort.p;
-    FS_HIP(ctx->st_scratch.ensure(stats_work_bytes(S, T) + 256));
-    w.scratch = ctx->st_scratch.p;
-    // outputs
-    const size_t SS = (size_t)S * S;
-    const size_t out_sizes[16] = {N * 8, (size_t)(S + 1) * 4, N * 8, (size_t)S * 16, (size_t)S * 8, (size_t)S * 12, (size_t)S * 8,
-                                  (size_t)65536 * S * 8, (size_t)1600 * S * 8, (size_t)S * T * 8, (size_t)S * 16, SS * 4, SS * 16,
-                                  N * 4, (size_t)S * 32, 4};
-    size_t out_total = 0;
-    for (size_t b : out_sizes) out_total += up8(b);
-    FS_HIP(ctx->st_out.ensure(out_total));
-    char *od[16];
-    {
-        char *p = ctx->st_out.as<char>();
-        for (int i = 0; i < 16; ++i) { od[i] = p; p += up8(out_sizes[i]); }
-    }
-    StatsOut out{};
-    out.surfaces = reinterpret_cast<int64_t *>(od[0]);
-    out.patch_point_offsets = reinterpret_cast<int32_t *>(od[1]);
-    out.patch_points = reinterpret_cast<float *>(od[2]);
-    out.avg_pos = reinterpret_cast<double *>(od[3]);
-    out.counts = reinterpret_cast<double *>(od[4]);
-    out.centroids = reinterpret_cast<float *>(od[5]);
-    out.centroid_idx = reinterpret_cast<int32_t *>(od[6]);
-    out.hist_color = reinterpret_cast<double *>(od[7]);
-    out.hist_angle = reinterpret_cast<double *>(od[8]);
-    out.hist_texture = reinterpret_cast<double *>(od[9]);
-    out.avg_angles = reinterpret_cast<double *>(od[10]);
-    out.nb_count = reinterpret_cast<uint32_t *>(od[11]);
-    out.nb_sum = reinterpret_cast<unsigned long long *>(od[12]);
-    out.norm = reinterpret_cast<float *>(od[13]);
-    out.depth_extend = reinterpret_cast<float *>(od[14]);
-    out.err = reinterpret_cast<int *>(od[15]);
-    hipError_t e = launch_surface_stats(in, w, out, H, W, S, T, ctx->stream);
-    if (e != hipSuccess) return ctx->fail(e, "fs_surface_stats: launch");
-    int err = 0;
-    std::vector<uint32_t> nbc(SS);
-    std::vector<unsigned long long> nbs(2 * SS);
-    void *host_out[11] = {surfaces_out, patch_point_offsets, patch_points, avg_pos, counts, centroids, centroid_indices, hist_color,
-                          hist_angle, hist_texture, avg_angles};
-    for (int i = 0; i < 11; ++i)
+    void *const none[kStatsOutputs] = {};
+    char *od[kStatsOutputs];
+    size_t out_sizes[kStatsOutputs];
+    if (surface_stats_core(ctx, "fs_surface_stats", S, T, in, none, od, out_sizes)) return -1;
+    void *host_out[kStatsOutputs] = {surfaces_out, patch_point_offsets, patch_points, avg_pos, counts, centroids, centroid_indices,
+                                     hist_color, hist_angle, hist_texture, avg_angles, neighbors, border_centers, norm, depth_extend};
+    for (int i = 0; i < kStatsOutputs; ++i)
         if (host_out[i]) FS_HIP(hipMemcpyAsync(host_out[i], od[i], out_sizes[i], hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipMemcpyAsync(nbc.data(), od[11], out_sizes[11], hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipMemcpyAsync(nbs.data(), od[12], out_sizes[12], hipMemcpyDeviceToHost, ctx->stream));
-    if (norm) FS_HIP(hipMemcpyAsync(norm, od[13], out_sizes[13], hipMemcpyDeviceToHost, ctx->stream));
-    if (depth_extend) FS_HIP(hipMemcpyAsync(depth_extend, od[14], out_sizes[14], hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipMemcpyAsync(&err, od[15], 4, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    if (err == 1) return ctx->fail("fs_surface_stats: a label lies outside [0, num_surfaces)");
-    if (err == 2) return ctx->fail("fs_surface_stats: Lab a/b + 127 rounds outside [0, 255]");
-    if (err == 3) return ctx->fail("fs_surface_stats: angle outside [-pi, pi]");
-    // S x S post-processing of determine_neighboring_surfaces_and_border_centers (process_surfaces.py:56-68):
-    // every adjacent pair was counted once, in the direction it was met; the reference adds it to both entries
-    if (neighbors && border_centers) {
-        for (int i = 0; i < S; ++i)
-            for (int j = 0; j < S; ++j) {
-                const size_t a = (size_t)i * S + j, b = (size_t)j * S + i;
-                neighbors[a] = (double)(nbc[a] + nbc[b]);
-                border_centers[2 * a] = (double)(nbs[2 * a] + nbs[2 * b]);
-                border_centers[2 * a + 1] = (double)(nbs[2 * a + 1] + nbs[2 * b + 1]);
-            }
-        for (int j = 0; j < S; ++j) {
-            neighbors[j] = 0; neighbors[(size_t)j * S] = 0;
-            border_centers[2 * j] = border_centers[2 * j + 1] = 0;
-            border_centers[2 * (size_t)j * S] = border_centers[2 * (size_t)j * S + 1] = 0;
-        }
-        for (int i = 0; i < S; ++i) {
-            neighbors[(size_t)i * S + i] = 0;
-            border_centers[2 * ((size_t)i * S + i)] = border_centers[2 * ((size_t)i * S + i) + 1] = 0;
-            for (int j = 0; j < S; ++j)
-                if (neighbors[(size_t)i * S + j] < 4) neighbors[(size_t)i * S + j] = neighbors[(size_t)j * S + i] = 1;
-        }
-        for (size_t k = 0; k < SS; ++k) {
-            border_centers[2 * k] /= 2 * neighbors[k];
-            border_centers[2 * k + 1] /= 2 * neighbors[k];
-        }
-    }
     return 0;
+}
+
+int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surfaces, const int64_t *d_patches,
+                         const int32_t *d_depth_edges, const float *d_points_3d, const float *d_angles, const double *d_lab,
+                         const float *d_texture, int texture_dim, int64_t *d_surfaces_out, int32_t *d_patch_point_offsets,
+                         float *d_patch_points, double *d_avg_pos, double *d_counts, float *d_centroids, int32_t *d_centroid_indices,
+                         double *d_hist_color, double *d_hist_angle, double *d_hist_texture, double *d_avg_angles,
+                         double *d_neighbors, double *d_border_centers, float *d_norm, float *d_depth_extend)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    const int S = num_surfaces, T = texture_dim;
+    if (stats_check_args(ctx, "fs_surface_stats_dev", S, T, d_texture != nullptr,
+                         d_surfaces && d_patches && d_depth_edges && d_points_3d && d_angles && d_lab))
+        return -1;
+    StatsIn in{};
+    in.surfaces = d_surfaces;
+    in.patches = d_patches;
+    in.depth_edges = d_depth_edges;
+    in.points_3d = d_points_3d;
+    in.angles = d_angles;
+    in.lab = d_lab;
+    in.texture = d_texture;
+    void *const user_out[kStatsOutputs] = {d_surfaces_out, d_patch_point_offsets, d_patch_points, d_avg_pos, d_counts, d_centroids,
+                                           d_centroid_indices, d_hist_color, d_hist_angle, d_hist_texture, d_avg_angles, d_neighbors,
+                                           d_border_centers, d_norm, d_depth_extend};
+    char *od[kStatsOutputs];
+    size_t out_sizes[kStatsOutputs];
+    return surface_stats_core(ctx, "fs_surface_stats_dev", S, T, in, user_out, od, out_sizes) ? -1 : 0;
 }
 
 int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int S, int pool_h, int pool_w, int stride_h, int stride_w,

@@ -94,8 +94,8 @@ struct StatsOut {
     float *centroids;                    // [S][3]
     int32_t *centroid_idx;               // [S][2] (y, x)
     double *hist_color, *hist_angle, *hist_texture, *avg_angles;   // [256][256][S], [40][40][S], [S][T], [S][2]
-    uint32_t *nb_count;                  // [S][S] one-directional pair counts (row = the pixel, column = its lower/right neighbour)
-    unsigned long long *nb_sum;          // [S][S][2] sums of the doubled border coordinates
+    double *neighbors;                   // [S][S] symmetric pair counts after the "< 4 -> 1" rule
+    double *border_centers;              // [S][S][2]
     float *norm;                         // [H][W]
     float *depth_extend;                 // [S][4][2]
     int *err;                            // 0 ok, 1 label out of range, 2 colour bin out of range, 3 angle bin out of range

@@ -6,7 +6,7 @@
 //   determine_surface_patch_centroids                  :81-93    first minimum of an fp64 distance
 //   remove_disconnected_components                     :8-28     label components instead of flood fills
 //   determine_histograms_and_average_normals           :245-297
-//   determine_neighboring_surfaces_and_border_centers  :31-59    (the S x S post-processing runs on the host)
+//   determine_neighboring_surfaces_and_border_centers  :31-68
 //   calculate_depth_extend                             :332-346
 // All of it is HBM-bound integer / byte work: one pass per dependency level, per-block
 // privatisation in LDS of everything indexed by label, one global atomic per (block, label).
@@ -350,6 +350,28 @@ __global__ __launch_bounds__(SB) void stats_finalize_kernel(const uint32_t *__re
     }
 }
 
+// The S x S tail of determine_neighboring_surfaces_and_border_centers (process_surfaces.py:56-68).  Every adjacent
+// pair was counted once, in the direction it was met; the reference adds it to both entries, zeroes row 0, column 0
+// and the diagonal, replaces every count below 4 by 1 (the diagonal and row/column 0 included: they are 0 by then)
+// and divides the coordinate sums by twice the count.
+__global__ __launch_bounds__(SB) void stats_neighbors_kernel(const uint32_t *__restrict__ nb_count,
+                                                             const unsigned long long *__restrict__ nb_sum,
+                                                             double *__restrict__ neighbors, double *__restrict__ border_centers, int S)
+{
+    const size_t a = (size_t)blockIdx.x * SB + threadIdx.x;
+    if (a >= (size_t)S * S) return;
+    const int i = (int)(a / S), j = (int)(a - (size_t)i * S);
+    const size_t b = (size_t)j * S + i;
+    const bool dead = i == 0 || j == 0 || i == j;
+    double n = dead ? 0.0 : (double)(nb_count[a] + nb_count[b]);
+    const double sx = dead ? 0.0 : (double)(nb_sum[2 * a] + nb_sum[2 * b]);
+    const double sy = dead ? 0.0 : (double)(nb_sum[2 * a + 1] + nb_sum[2 * b + 1]);
+    if (n < 4) n = 1;
+    neighbors[a] = n;
+    border_centers[2 * a] = sx / (2 * n);
+    border_centers[2 * a + 1] = sy / (2 * n);
+}
+
 __global__ __launch_bounds__(SB) void stats_fill_kernel(uint32_t *__restrict__ a, size_t n, uint32_t even, uint32_t odd)
 {
     const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
@@ -426,8 +448,8 @@ hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const Sta
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((n_fin + SB - 1) / SB)), dim3(SB), 0, st, hist_color, hist_angle, angle_sum,
                        cnt, tex_sum, tex_cnt, extent, out.hist_color, out.hist_angle, out.hist_texture, out.avg_angles,
                        out.depth_extend, S, T);
-    if ((e = hipMemcpyAsync(out.nb_count, nb_count, 4 * (size_t)S * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(out.nb_sum, nb_sum, 16 * (size_t)S * S, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(stats_neighbors_kernel, dim3((unsigned)(((size_t)S * S + SB - 1) / SB)), dim3(SB), 0, st, nb_count, nb_sum,
+                       out.neighbors, out.border_centers, S);
     if ((e = hipMemcpyAsync(out.err, err, 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
     return hipGetLastError();
 }

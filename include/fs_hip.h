@@ -150,14 +150,26 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
  *   determine_neighboring_surfaces_and_border_centers (:31-68) -> neighbors float64 [S][S] (pair counts after the
  *       "< 4 -> 1" rule; the neighbour list of :70-77 is neighbors[i][j] > 3 for j >= 1), border_centers float64 [S][S][2]
  *   norm (:686) float32 [H][W], calculate_depth_extend (:332-346) -> depth_extend float32 [S][4][2]
- * S = num_surfaces; every label of surfaces and patches must lie in [0, S).  Output pointers may be NULL
- * (neighbors and border_centers only together). */
+ * S = num_surfaces; every label of surfaces and patches must lie in [0, S).  Output pointers may be NULL. */
 int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, const int64_t *patches,
                      const int32_t *depth_edges, const float *points_3d, const float *angles, const double *lab,
                      const float *texture, int texture_dim, int64_t *surfaces_out, int32_t *patch_point_offsets,
                      float *patch_points, double *avg_pos, double *counts, float *centroids, int32_t *centroid_indices,
                      double *hist_color, double *hist_angle, double *hist_texture, double *avg_angles, double *neighbors,
                      double *border_centers, float *norm, float *depth_extend);
+
+/* The same stage with every array resident in device memory, for callers that keep the outputs of
+ * fs_find_surfaces_batch_dev where they are: the arguments and layouts are those of fs_surface_stats, frame by
+ * frame (process_surfaces.py:672-687 is a per-frame function), but every pointer is a device pointer.  Output
+ * pointers may be NULL.  Work is enqueued on the context's stream; the call synchronises once to read the
+ * range-check flag (labels, colour bins, angle bins) and returns its error like fs_surface_stats. */
+int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surfaces, const int64_t *d_patches,
+                         const int32_t *d_depth_edges, const float *d_points_3d, const float *d_angles, const double *d_lab,
+                         const float *d_texture, int texture_dim, int64_t *d_surfaces_out, int32_t *d_patch_point_offsets,
+                         float *d_patch_points, double *d_avg_pos, double *d_counts, float *d_centroids,
+                         int32_t *d_centroid_indices, double *d_hist_color, double *d_hist_angle, double *d_hist_texture,
+                         double *d_avg_angles, double *d_neighbors, double *d_border_centers, float *d_norm,
+                         float *d_depth_extend);
 
 /* chi_squared_distances_model_2D(pool_size, strides) (image_processing_models_GPU.py:189-200) applied to
  * one histogram stack: hist float64 [A][B][S] (e.g. hist_color [256][256][S] with pool (10,10), strides

@@ -1,0 +1,38 @@
+"""The whole headline workload (all 111 OSD frames in one batch, the configuration bench.py times) through
+the C ABI, against the committed oracle results of tests/golden/osd_all.npz
+(tests/golden/make_golden_osd_all.py): the reference's main.find_surfaces_for_dataset (main.py:25-26)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import osd_frame
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "osd_all.npz")
+
+
+def test_all_osd_frames_in_one_batch():
+    g = np.load(GOLDEN)
+    n = len(g["num_surfaces"])
+    frames = [osd_frame(i) for i in range(n)]
+    d = np.stack([f[0] for f in frames]).astype(np.uint16)
+    c = np.stack([f[1] for f in frames]).astype(np.uint8)
+    from imagesegmentation_amd._lib import Context
+    with Context(480, 640, max_batch=n) as ctx:
+        got = ctx.find_surfaces_batch(d, c)
+    assert np.array_equal(got["num_surfaces"], g["num_surfaces"])
+    worst = 1.0
+    for i in range(n):
+        # integer stages: bit-exact
+        assert zlib.crc32(np.ascontiguousarray(got["patches"][i].astype(np.int32)).tobytes()) == g["crc_patches"][i], i
+        assert zlib.crc32(np.ascontiguousarray(got["depth_edges"][i].astype(np.int8)).tobytes()) == g["crc_edges"][i], i
+        # CRF labels: equal except where the oracle's two largest probabilities are within 1e-5 relative
+        dis = got["surfaces"][i] != g["surfaces"][i]
+        if dis.any():
+            tie = np.unpackbits(g["near_tie"][i])[:dis.size].reshape(dis.shape).astype(bool)
+            assert not (dis & ~tie).any(), f"frame {i}: {int((dis & ~tie).sum())} label differences that are not ties"
+        worst = min(worst, 1.0 - dis.mean())
+    assert worst >= 0.999, worst
