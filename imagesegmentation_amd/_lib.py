@@ -43,6 +43,7 @@ SIGNATURES = {
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
     "fs_surface_stats_dev": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
     "fs_chi_squared_distances": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fs_chi_squared_distances_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "fs_nearest_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_set_timing": (_i, [_vp, _i]),
@@ -363,6 +364,13 @@ class Context:
         self._check(self._lib.fs_chi_squared_distances(self._h, _ptr(hist), A, B, S, int(pool_size[0]), int(pool_size[1]),
                                                        int(strides[0]), int(strides[1]), _ptr(out)))
         return out
+
+    def chi_squared_distances_dev(self, d_hist, shape, d_out, pool_size=(1, 1), strides=(1, 1)):
+        """fs_chi_squared_distances_dev: d_hist float64 [A][B][S] and d_out float32 [S][S] are device pointers
+        (integers), shape = (A, B, S).  Enqueues on the context's stream; does not synchronise."""
+        A, B, S = (int(v) for v in shape)
+        self._check(self._lib.fs_chi_squared_distances_dev(self._h, d_hist, A, B, S, int(pool_size[0]), int(pool_size[1]),
+                                                           int(strides[0]), int(strides[1]), d_out))
 
     def overlap_counts(self, annotation, detected, num_annotations, num_detections):
         a = _arr(annotation, np.int64, (self.H, self.W))

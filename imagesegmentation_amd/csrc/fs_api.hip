@@ -44,7 +44,7 @@ struct fs_ctx {
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
     // per-surface statistics (one frame in flight)
-    DevBuf st_in, st_work, st_sort, st_scratch, st_out;
+    DevBuf st_in, st_work, st_sort, st_scratch, st_out, st_pool;
 
     // timing
     unsigned timing = 0;   // bit g set: record events around kernel group g
@@ -454,7 +454,7 @@ void fs_destroy(fs_ctx *ctx)
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
-                      &ctx->st_scratch, &ctx->st_out, &ctx->simH, &ctx->qa, &ctx->qb,
+                      &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
                       &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
@@ -1036,6 +1036,23 @@ int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int 
     FS_HIP(hipGetLastError());
     FS_HIP(hipMemcpyAsync(out, ctx->st_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_chi_squared_distances_dev(fs_ctx *ctx, const double *d_hist, int A, int B, int S, int pool_h, int pool_w, int stride_h,
+                                 int stride_w, float *d_out)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (!d_hist || !d_out || A < 1 || B < 1 || S < 1 || pool_h < 1 || pool_w < 1 || stride_h < 1 || stride_w < 1 || pool_h > A ||
+        pool_w > B)
+        return ctx->fail("fs_chi_squared_distances_dev: bad shape");
+    if (S > 65535) return ctx->fail("fs_chi_squared_distances_dev: too many surfaces");
+    const int PA = (A - pool_h) / stride_h + 1, PB = (B - pool_w) / stride_w + 1;
+    // a buffer of its own: st_scratch may still hold what an earlier call on this stream left for a later one
+    FS_HIP(ctx->st_pool.ensure((size_t)S * PA * PB * 4));
+    launch_chi_squared(d_hist, ctx->st_pool.as<float>(), d_out, A, B, S, pool_h, pool_w, stride_h, stride_w, ctx->stream);
+    FS_HIP(hipGetLastError());
     return 0;
 }
 

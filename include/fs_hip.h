@@ -180,6 +180,12 @@ int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surface
 int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int S, int pool_h, int pool_w,
                              int stride_h, int stride_w, float *out);
 
+/* The same on a histogram stack that is already in device memory (the hist_color / hist_angle / hist_texture
+ * outputs of fs_surface_stats_dev); d_out float32 [S][S] is a device pointer.  The work is enqueued on the
+ * context's stream and the call returns without synchronising. */
+int fs_chi_squared_distances_dev(fs_ctx *ctx, const double *d_hist, int A, int B, int S, int pool_h, int pool_w,
+                                 int stride_h, int stride_w, float *d_out);
+
 /* The pixel loop of evaluate_models.extract_IoU_information (evaluate_models.py:28-35): overlap float64
  * [num_detections][num_annotations] = number of pixels with (detected == o, annotation == a); the row and
  * column sums are the two count vectors of :33-34.  int64 [H][W] inputs, host pointers. */

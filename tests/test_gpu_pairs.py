@@ -3,7 +3,7 @@ and label-pair overlap counts / IoU (integers: exact)."""
 import numpy as np
 import pytest
 
-from conftest import osd_frame
+from conftest import DeviceArrays, osd_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,19 @@ def test_chi_squared_distances(oracle):
         assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
         assert np.array_equal(got, got.T) and (np.diag(got) == 0).all()
         assert (got[1:, 1:] > 0).any()
+    # the histograms where fs_surface_stats_dev leaves them (device memory): same kernels, same result
+    from imagesegmentation_amd._lib import Context
+    mem = DeviceArrays()
+    try:
+        with Context(480, 640) as ctx:
+            for hist, pool, stride in cases:
+                want = ctx.chi_squared_distances(hist, pool, stride)
+                d_out = mem.alloc(want.nbytes)
+                ctx.chi_squared_distances_dev(mem.upload(hist), hist.shape, d_out, pool, stride)
+                assert mem.hip.hipDeviceSynchronize() == 0
+                assert np.array_equal(mem.download(d_out, want), want)
+    finally:
+        mem.free()
     rng = np.random.default_rng(1)
     h1 = rng.random((256, S))
     h1[h1 < 0.5] = 0

@@ -6,7 +6,7 @@ within 1e-12 relative, since the order of additions differs."""
 import numpy as np
 import pytest
 
-from conftest import osd_frame
+from conftest import DeviceArrays, osd_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -107,40 +107,6 @@ def test_process_surfaces_mirror_keys(oracle):
     assert np.allclose(np.linalg.norm(data["avg_normals"][1:], axis=-1), 1)
 
 
-class _DeviceArrays:
-    """Device memory through the HIP runtime the library itself is linked against (plain hipMalloc / hipMemcpy by
-    ctypes), standing in for a caller's own allocations."""
-
-    def __init__(self):
-        import ctypes
-        self.c = ctypes
-        self.hip = ctypes.CDLL("libamdhip64.so.7")
-        self.ptrs = []
-
-    def alloc(self, nbytes, fill=0xA5):
-        p = self.c.c_void_p()
-        assert self.hip.hipMalloc(self.c.byref(p), self.c.c_size_t(max(nbytes, 1))) == 0
-        assert self.hip.hipMemset(p, fill, self.c.c_size_t(max(nbytes, 1))) == 0
-        self.ptrs.append(p)
-        return p.value
-
-    def upload(self, a):
-        a = np.ascontiguousarray(a)
-        p = self.alloc(a.nbytes)
-        assert self.hip.hipMemcpy(self.c.c_void_p(p), a.ctypes.data_as(self.c.c_void_p), self.c.c_size_t(a.nbytes), 1) == 0
-        return p
-
-    def download(self, p, like):
-        out = np.empty_like(like)
-        assert self.hip.hipMemcpy(out.ctypes.data_as(self.c.c_void_p), self.c.c_void_p(p), self.c.c_size_t(out.nbytes), 2) == 0
-        return out
-
-    def free(self):
-        for p in self.ptrs:
-            self.hip.hipFree(p)
-        self.ptrs = []
-
-
 def test_surface_stats_device_pointers(oracle):
     """fs_surface_stats_dev on arrays resident in HBM: the outputs equal the host-pointer entry point's (same
     kernels; bit for bit except the two float64 sums whose order of additions is not fixed); outputs that are not
@@ -151,7 +117,7 @@ def test_surface_stats_device_pointers(oracle):
     host_in = (ref["surfaces"], ref["patches"], ref["depth_edges"], ref["points_3d"], ref["angles"], lab, tex)
     with Context(480, 640) as ctx:
         want = ctx.surface_stats(*host_in, S)
-        mem = _DeviceArrays()
+        mem = DeviceArrays()
         try:
             d_in = [mem.upload(a) for a in host_in]
             d_out = {k: mem.alloc(v.nbytes) for k, v in want.items()}
