@@ -720,7 +720,6 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     if (!ctx->have_params) return ctx->fail("fs_find_surfaces: call fs_set_gauss_params first");
     if (!d_depth || !d_rgb) return ctx->fail("fs_find_surfaces: depth and rgb are required");
     const int H = ctx->H, W = ctx->W;
-    const size_t N = ctx->N();
     float *angles = d_angles ? d_angles : ctx->angles.as<float>();
     float *vectors = d_vectors ? d_vectors : ctx->normals.as<float>();
     float *points = d_points ? d_points : ctx->points.as<float>();
