@@ -1371,6 +1371,9 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
         return hipErrorInvalidValue;
     }
     if (g.r == 7 && uniform) { FS_FUSED_CASES_U(7, 16) }
+    // other radii with uniform constants: run-time window size, but still no weight table
+    if (uniform && th == 16) { FS_FUSED_CASES_U(0, 16) }
+    if (uniform && th == 8) { FS_FUSED_CASES_U(0, 8) }
     if (th == 16) { FS_FUSED_CASES(0, 16) }
     if (th == 8) { FS_FUSED_CASES(0, 8) }
 #undef FS_FUSED_CASES
