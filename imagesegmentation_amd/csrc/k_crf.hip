@@ -660,6 +660,24 @@ __device__ __forceinline__ void finish_pixel_compact(float (&m)[NC], const int *
             }
         }
     }
+    if (last) {
+        // Only the label is wanted (:531-532).  The softmax is monotone, so its first maximum is the first maximum of
+        // its argument, except where two arguments differ by so little that their exponentials round to the same
+        // float: such labels are numerically tied and the choice between them carries no information.
+        int best = 0;
+        float bestv = -INFINITY;
+        if (!invalid) {                                                  // Q[depth == 0] = 0: argmax of zeros is label 0
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c < CE) {
+                    const int lab = s_list[REC_LAB + c];
+                    if (m[c] > bestv || (m[c] == bestv && lab < best)) { bestv = m[c]; best = lab; }
+                }
+            }
+        }
+        d.surfaces[wi] = best == S - 1 ? 0 : best;
+        return;
+    }
     float den = 0.0f;
 #pragma unroll
     for (int g = 0; g < NC / 4; ++g) {
