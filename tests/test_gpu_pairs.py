@@ -36,6 +36,10 @@ def test_chi_squared_distances(oracle):
                 ctx.chi_squared_distances_dev(mem.upload(hist), hist.shape, d_out, pool, stride)
                 assert mem.hip.hipDeviceSynchronize() == 0
                 assert np.array_equal(mem.download(d_out, want), want)
+            with pytest.raises(RuntimeError, match="bad shape"):
+                ctx.chi_squared_distances_dev(None, (4, 4, 2), mem.alloc(16))
+            with pytest.raises(RuntimeError, match="bad shape"):
+                ctx.chi_squared_distances_dev(mem.alloc(256), (4, 4, 2), mem.alloc(16), pool_size=(5, 1))
     finally:
         mem.free()
     rng = np.random.default_rng(1)

@@ -137,5 +137,9 @@ def test_surface_stats_device_pointers(oracle):
             bad[0, 0] = S
             with pytest.raises(RuntimeError):
                 ctx.surface_stats_dev(S, mem.upload(bad), *d_in[1:6])
+            with pytest.raises(RuntimeError, match="null input"):
+                ctx.surface_stats_dev(S, None, *d_in[1:6])
+            with pytest.raises(RuntimeError, match="num_surfaces"):
+                ctx.surface_stats_dev(0, *d_in[:6])
         finally:
             mem.free()
