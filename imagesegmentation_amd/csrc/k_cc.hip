@@ -326,6 +326,95 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_relabel_kernel(const int32_t *__r
     if (labels32) labels32[fo + p] = id;
 }
 
+// ---- the same three passes with four consecutive pixels per lane (16-byte loads and stores) for frames whose
+// pixel count is a multiple of four; the block still covers CC_BLOCK pixels, so the block sums and their scan are
+// those of the one-pixel kernels ----
+constexpr int CC_VT = CC_BLOCK / 4;     // threads per block of the four-pixel kernels
+
+__device__ __forceinline__ void survivors4(const int32_t *parent, const int32_t *count, size_t i, int p, int thr, bool (&s)[4])
+{
+    const int4 par = *reinterpret_cast<const int4 *>(parent + i);
+    const int4 cnt = *reinterpret_cast<const int4 *>(count + i);   // meaningful at roots only; the memory exists everywhere
+    s[0] = par.x == p && cnt.x > thr;
+    s[1] = par.y == p + 1 && cnt.y > thr;
+    s[2] = par.z == p + 2 && cnt.z > thr;
+    s[3] = par.w == p + 3 && cnt.w > thr;
+}
+
+__global__ __launch_bounds__(CC_VT) void cc_blocksum4_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
+                                                             int32_t *__restrict__ blocksum, int N, int thr)
+{
+    __shared__ int wsum[CC_VT / 64];
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x * 4;
+    bool s[4] = {false, false, false, false};
+    if (p < N) survivors4(parent, count, fo + p, p, thr, s);
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t += __popcll(__ballot(s[k]));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < CC_VT / 64; ++i) tot += wsum[i];
+        blocksum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(CC_VT) void cc_rank4_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
+                                                         const int32_t *__restrict__ blocksum, int32_t *__restrict__ newid, int N,
+                                                         int thr)
+{
+    __shared__ int wsum[CC_VT / 64];
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool s[4] = {false, false, false, false};
+    if (p < N) survivors4(parent, count, fo + p, p, thr, s);
+    const unsigned long long low = (1ull << lane) - 1ull;
+    int t = 0, mine = 0;                        // survivors of the wave, and of the lanes below this one
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long b = __ballot(s[k]);
+        t += __popcll(b);
+        mine += __popcll(b & low);
+    }
+    if (lane == 0) wsum[wv] = t;
+    __syncthreads();
+    int run = blocksum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] + mine;
+    for (int i = 0; i < wv; ++i) run += wsum[i];
+    if (p < N) {
+        int4 id;
+        id.x = s[0] ? ++run : 0;
+        id.y = s[1] ? ++run : 0;
+        id.z = s[2] ? ++run : 0;
+        id.w = s[3] ? ++run : 0;
+        *reinterpret_cast<int4 *>(newid + fo + p) = id;
+    }
+}
+
+__global__ __launch_bounds__(CC_VT) void cc_relabel4_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ newid,
+                                                            int64_t *__restrict__ labels64, int32_t *__restrict__ labels32, int N)
+{
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x * 4;
+    if (p >= N) return;
+    const int4 par = *reinterpret_cast<const int4 *>(parent + fo + p);
+    int root[4] = {par.x, par.y, par.z, par.w}, id[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (root[k] >= 0) root[k] = parent[fo + root[k]];      // tile-local root -> root
+#pragma unroll
+    for (int k = 0; k < 4; ++k) id[k] = root[k] >= 0 ? newid[fo + root[k]] : 0;
+    if (labels64) {
+        longlong2 *o = reinterpret_cast<longlong2 *>(labels64 + fo + p);
+        o[0] = make_longlong2(id[0], id[1]);
+        o[1] = make_longlong2(id[2], id[3]);
+    }
+    if (labels32) *reinterpret_cast<int4 *>(labels32 + fo + p) = make_int4(id[0], id[1], id[2], id[3]);
+}
+
 }  // namespace
 
 template <typename T, bool SIZES>
@@ -348,6 +437,18 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const dim3 grid(nblk, n), block(CC_BLOCK);
     launch_local_and_border<uint8_t, true>(mask, w.parent, w.count, w.newid, n, H, W, st);   // newid holds the local sizes until cc_rank
     hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
+    // four pixels per lane when every frame starts on a 16-byte boundary in all arrays
+    const bool vec = N % 4 == 0 && reinterpret_cast<uintptr_t>(w.parent) % 16 == 0 && reinterpret_cast<uintptr_t>(w.count) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(w.newid) % 16 == 0 && reinterpret_cast<uintptr_t>(labels64) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(labels32) % 16 == 0;
+    if (vec) {
+        const dim3 block4(CC_VT);
+        hipLaunchKernelGGL(cc_blocksum4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
+        hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
+        hipLaunchKernelGGL(cc_rank4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
+        hipLaunchKernelGGL(cc_relabel4_kernel, grid, block4, 0, st, w.parent, w.newid, labels64, labels32, N);
+        return;
+    }
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
     hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
