@@ -341,6 +341,25 @@ __device__ __forceinline__ void survivors4(const int32_t *parent, const int32_t 
     s[3] = par.w == p + 3 && cnt.w > thr;
 }
 
+__global__ __launch_bounds__(CC_VT) void cc_sum_sizes4_kernel(int32_t *__restrict__ parent, int32_t *__restrict__ count,
+                                                              const int32_t *__restrict__ lsize, int N)
+{
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x * 4;
+    if (p >= N) return;
+    const int4 l4 = *reinterpret_cast<const int4 *>(lsize + fo + p);
+    const int ls[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ls[k] <= 0) continue;
+        int a = p + k;
+        int q = ld_parent(parent + fo, a);
+        while (q != a) { a = q; q = ld_parent(parent + fo, a); }
+        if (a != p + k) parent[fo + p + k] = a;
+        atomicAdd(count + fo + a, ls[k]);
+    }
+}
+
 __global__ __launch_bounds__(CC_VT) void cc_blocksum4_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
                                                              int32_t *__restrict__ blocksum, int N, int thr)
 {
@@ -436,19 +455,20 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const int nblk = (int)cc_blocks_per_image(H, W);
     const dim3 grid(nblk, n), block(CC_BLOCK);
     launch_local_and_border<uint8_t, true>(mask, w.parent, w.count, w.newid, n, H, W, st);   // newid holds the local sizes until cc_rank
-    hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
     // four pixels per lane when every frame starts on a 16-byte boundary in all arrays
     const bool vec = N % 4 == 0 && reinterpret_cast<uintptr_t>(w.parent) % 16 == 0 && reinterpret_cast<uintptr_t>(w.count) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(w.newid) % 16 == 0 && reinterpret_cast<uintptr_t>(labels64) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(labels32) % 16 == 0;
     if (vec) {
         const dim3 block4(CC_VT);
+        hipLaunchKernelGGL(cc_sum_sizes4_kernel, grid, block4, 0, st, w.parent, w.count, w.newid, N);
         hipLaunchKernelGGL(cc_blocksum4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
         hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
         hipLaunchKernelGGL(cc_rank4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
         hipLaunchKernelGGL(cc_relabel4_kernel, grid, block4, 0, st, w.parent, w.newid, labels64, labels32, N);
         return;
     }
+    hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
     hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
