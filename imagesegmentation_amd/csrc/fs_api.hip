@@ -287,7 +287,8 @@ constexpr int kPipeChunk = 16;  // frames per upload / compute / download step o
 // listed labels per tile (host arrays).  Frames are processed in groups; inside a group all
 // frames of one kernel variant (channel class) share a launch.
 int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
-                  const int32_t *d_labels32, const int *S, const int *max_active, int iterations, int64_t *d_surfaces)
+                  const int32_t *d_labels32, const int *S, const int *max_active, int iterations, int64_t *d_surfaces,
+                  bool angle_features_ready = false)
 {
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
@@ -379,7 +380,8 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
     if (fused) {
         ScopedTimer t(ctx, G_SIM);
-        launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->params, ctx->stream);
+        launch_crf_pack_features(d_depth, d_rgb, angle_features_ready ? nullptr : d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N,
+                                 ctx->params, ctx->stream);
     }
     for (int gi = 0; gi < ngroups; ++gi) {
         const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
@@ -572,7 +574,7 @@ int fs_normals(fs_ctx *ctx, int n, const float *smoothed, float *angles, float *
     FS_HIP(hipMemcpyAsync(ctx->smoothed.p, smoothed, px * 4, hipMemcpyHostToDevice, ctx->stream));
     launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), ctx->points.as<float>(),
                    ctx->normals.as<float>(), ctx->raw.as<float>(), n, ctx->H, ctx->W, ctx->stream);
-    launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), ctx->angles.as<float>(), n, ctx->H, ctx->W, ctx->stream);
+    launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), ctx->angles.as<float>(), nullptr, 1.0f, n, ctx->H, ctx->W, ctx->stream);
     FS_HIP(hipGetLastError());
     if (angles) FS_HIP(hipMemcpyAsync(angles, ctx->angles.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (vectors) FS_HIP(hipMemcpyAsync(vectors, ctx->normals.p, px * 12, hipMemcpyDeviceToHost, ctx->stream));
@@ -726,12 +728,15 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     int64_t *patches = d_patches ? d_patches : ctx->patches64.as<int64_t>();
     int32_t *edges = d_edges ? d_edges : ctx->edges.as<int32_t>();
     int64_t *surfaces = d_surfaces ? d_surfaces : ctx->surfaces64.as<int64_t>();
+    const bool fused_crf = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;     // as run_crf_batch decides
     {
         ScopedTimer t(ctx, G_STENCIL);
         launch_smooth_depth_u16(d_depth, ctx->smoothed.as<float>(), n, H, W, ctx->stream);                 // find_surfaces.py:505
         launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), points, vectors,
                        ctx->raw.as<float>(), n, H, W, ctx->stream);                                            // :507
-        launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, n, H, W, ctx->stream);
+        // the fused CRF update wants the angles once more, scaled, in its feature records: the filter writes both
+        launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, fused_crf ? ctx->featB.p : nullptr,
+                            crf_angle_feature_scale(ctx->params), n, H, W, ctx->stream);
     }
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
                     ctx->curv.as<uint8_t>(), true))                                                            // :513
@@ -743,7 +748,7 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
         S[i] = ns + 1;
         maxa[i] = ctx->counts_host[n + i];
     }
-    if (run_crf_batch(ctx, n, d_depth, d_rgb, angles, ctx->patches32.as<int32_t>(), S.data(), maxa.data(), 3, surfaces))   // :515-532
+    if (run_crf_batch(ctx, n, d_depth, d_rgb, angles, ctx->patches32.as<int32_t>(), S.data(), maxa.data(), 3, surfaces, fused_crf))   // :515-532
         return -1;
     FS_HIP(hipGetLastError());
     return 0;

@@ -49,7 +49,9 @@ void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, in
 void launch_smooth_depth_f32(const float *depth, float *out, int n, int H, int W, hipStream_t st);
 void launch_normals(const float *D, const float *tanx, const float *tany, float *points, float *normals,
                     float *raw_angles, int n, int H, int W, hipStream_t st);
-void launch_angle_filter(const float *raw_angles, const float *D, float *angles, int n, int H, int W, hipStream_t st);
+// feat (may be null): float2 [n][H][W] that receives feat_scale * angles, the angle half of the CRF feature records
+void launch_angle_filter(const float *raw_angles, const float *D, float *angles, void *feat, float feat_scale, int n, int H, int W,
+                         hipStream_t st);
 // todo: curvature_todo_ints(n, todo_cap) ints of work space for the pixels whose threshold test needs the
 // correctly rounded evaluation (a second, small kernel handles them); may be null
 void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
@@ -162,8 +164,10 @@ void launch_crf_lr_explicit(const float *unary, const float *Q, const float *f1,
 // wtab = per-offset weights [(2r+1)^2][4] = (w1', w2', w3', 0)
 int crf_fused_tile_height(int r);        // 16 or 8 rows (tile width 32), 0 if the window is too large for the fused kernel
 void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
+// angles == nullptr: featB already holds crf_angle_feature_scale(P) * angles (written by the angle filter)
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
                               size_t total, const CrfParams &P, hipStream_t st);
+float crf_angle_feature_scale(const CrfParams &P);
 // CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
 // planes of a tile's listed labels and of its representative are written (see k_crf.hip).
 // tile_queue: kCrfQueueBytes of device memory owned by the caller's context (the launch zeroes it; launches

@@ -1192,8 +1192,10 @@ __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     featA[q] = make_float4((float)depth[q], cscale * (float)rgb[3 * q], cscale * (float)rgb[3 * q + 1], cscale * (float)rgb[3 * q + 2]);
-    const float2 a = reinterpret_cast<const float2 *>(angles)[q];
-    featB[q] = make_float2(ascale * a.x, ascale * a.y);
+    if (angles) {
+        const float2 a = reinterpret_cast<const float2 *>(angles)[q];
+        featB[q] = make_float2(ascale * a.x, ascale * a.y);
+    }
 }
 
 template <int R, int PY, int NCH>
@@ -1330,10 +1332,12 @@ void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)
 static double fused_c2(const CrfParams &P) { return P.t23 / 2500.0 * 1.4426950408889634; }
 static double fused_c3(const CrfParams &P) { return 4.0 * P.t33 * 1.4426950408889634; }
 
+float crf_angle_feature_scale(const CrfParams &P) { return P.mode == 0 ? (float)std::sqrt(fused_c3(P)) : 1.0f; }
+
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
                               size_t total, const CrfParams &P, hipStream_t st)
 {
-    const float cs = P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f, as = P.mode == 0 ? (float)std::sqrt(fused_c3(P)) : 1.0f;
+    const float cs = P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f, as = crf_angle_feature_scale(P);
     hipLaunchKernelGGL(crf_pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, depth, rgb, angles,
                        reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total, cs, as);
 }

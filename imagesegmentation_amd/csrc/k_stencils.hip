@@ -193,8 +193,11 @@ constexpr int ATH = 16;   // tile height of the angle filter: 256 lanes x 2 vert
         V1 = V1 + m_ * a1;                                 \
     }
 
+// feat (may be null) receives the filtered angles times feat_scale: the angle half of the feature records the CRF
+// update stages, written here while the values are in registers instead of by a pass of its own.
 __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restrict__ raw, const float *__restrict__ D,
-                                                          float *__restrict__ angles, int H, int W)
+                                                          float *__restrict__ angles, float2 *__restrict__ feat, float feat_scale,
+                                                          int H, int W)
 {
     constexpr int R = 3;
     constexpr int LW = TW + 2 * R, LH = ATH + 2 * R;
@@ -270,9 +273,16 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
     };
     if (bandA) exact(0, dcA, sumsA, v0A, v1A);
     if (bandB) exact(1, dcB, sumsB, v0B, v1B);
-    float2 *out = reinterpret_cast<float2 *>(angles) + fo + (size_t)y * W + x;
-    out[0] = make_float2(div_no_nan(v0A, sumsA), div_no_nan(v1A, sumsA));
-    if (y + 1 < H) out[W] = make_float2(div_no_nan(v0B, sumsB), div_no_nan(v1B, sumsB));
+    const size_t o = fo + (size_t)y * W + x;
+    float2 *out = reinterpret_cast<float2 *>(angles) + o;
+    const float2 rA = make_float2(div_no_nan(v0A, sumsA), div_no_nan(v1A, sumsA));
+    const float2 rB = make_float2(div_no_nan(v0B, sumsB), div_no_nan(v1B, sumsB));
+    out[0] = rA;
+    if (y + 1 < H) out[W] = rB;
+    if (feat) {
+        feat[o] = make_float2(feat_scale * rA.x, feat_scale * rA.y);
+        if (y + 1 < H) feat[o + W] = make_float2(feat_scale * rB.x, feat_scale * rB.y);
+    }
 }
 #undef FS_ANGLE_TAP
 
@@ -505,9 +515,11 @@ void launch_normals(const float *D, const float *tanx, const float *tany, float 
 {
     hipLaunchKernelGGL(normals_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, tanx, tany, points, normals, raw_angles, H, W);
 }
-void launch_angle_filter(const float *raw_angles, const float *D, float *angles, int n, int H, int W, hipStream_t st)
+void launch_angle_filter(const float *raw_angles, const float *D, float *angles, void *feat, float feat_scale, int n, int H, int W,
+                         hipStream_t st)
 {
-    hipLaunchKernelGGL(angle_filter_kernel, dim3((W + TW - 1) / TW, (H + ATH - 1) / ATH, n), dim3(NT), 0, st, raw_angles, D, angles, H, W);
+    hipLaunchKernelGGL(angle_filter_kernel, dim3((W + TW - 1) / TW, (H + ATH - 1) / ATH, n), dim3(NT), 0, st, raw_angles, D, angles,
+                       reinterpret_cast<float2 *>(feat), feat_scale, H, W);
 }
 void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
                            float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st)
