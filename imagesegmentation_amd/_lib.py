@@ -28,6 +28,7 @@ SIGNATURES = {
     "fs_set_lr_params": (_i, [_vp, _vp]),
     "fs_set_kernel_size": (_i, [_vp, _i]),
     "fs_set_stream": (_i, [_vp, _vp]),
+    "fs_use_own_stream": (_i, [_vp]),
     "fs_stream": (_vp, [_vp]),
     "fs_smooth_depth": (_i, [_vp, _i, _vp, _vp]),
     "fs_normals": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -187,7 +188,11 @@ class Context:
         self._check(self._lib.fs_set_view_angles(self._h, float(view_x), float(view_y)))
 
     def set_stream(self, stream_ptr):
-        self._check(self._lib.fs_set_stream(self._h, stream_ptr))
+        """Run on the caller's stream; 0 / None is HIP's legacy default stream."""
+        self._check(self._lib.fs_set_stream(self._h, stream_ptr or None))
+
+    def use_own_stream(self):
+        self._check(self._lib.fs_use_own_stream(self._h))
 
     def stream(self):
         return self._lib.fs_stream(self._h)

@@ -1,14 +1,13 @@
-"""Frame geometry and data-set split: the constants the reference keeps in config.py:3-10,
-under the same names (callers star-import them)."""
+"""Frame geometry, data-set split and feature count: the constants of the reference's config.py:3-13
+under the same names (its callers star-import them)."""
 import math
 
-FRAME_SHAPE = (480, 640)                       # rows, columns of an OSD frame
-height, width = FRAME_SHAPE
+height, width = 480, 640                       # rows, columns of an OSD frame
 
-# field of view of the sensor in degrees -> radians, evaluated as degrees / 180 * pi
-_FIELD_OF_VIEW_DEG = {"x": 62.0, "y": 48.6}
-viewing_angle_x, viewing_angle_y = (_FIELD_OF_VIEW_DEG[axis] / 180 * math.pi for axis in ("x", "y"))
+viewing_angle_x = 62.0 / 180 * math.pi         # field of view of the sensor, radians
+viewing_angle_y = 48.6 / 180 * math.pi
 
-# the 15 held-out OSD frames; the other 96 of the 111 are the training split
-test_indices = [int(t) for t in "2 20 22 27 30 33 37 62 79 90 92 98 101 105 107".split()]
-train_indices = sorted(set(range(111)) - set(test_indices))
+test_indices = [2, 20, 22, 27, 30, 33, 37, 62, 79, 90, 92, 98, 101, 105, 107]   # the 15 held-out OSD frames
+train_indices = [i for i in range(111) if i not in test_indices]
+
+num_pairwise_features = 14                     # inputs of the pairwise surface classifiers (downstream of this stage)

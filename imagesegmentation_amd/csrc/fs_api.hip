@@ -474,6 +474,7 @@ int fs_set_view_angles(fs_ctx *ctx, double view_x, double view_y)
 {
     if (!ctx) return -1;
     if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));     // kernels in flight still read the tables this call rewrites
     ctx->view_x = view_x;
     ctx->view_y = view_y;
     return build_tables(ctx);
@@ -483,6 +484,7 @@ int fs_set_gauss_params(fs_ctx *ctx, const float p[13])
 {
     if (!ctx || !p) return -1;
     if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));     // kernels in flight still read the tables this call rewrites
     CrfParams &q = ctx->params;
     q.w1 = p[0]; q.w2 = p[1]; q.w3 = p[2]; q.bias = p[3];
     q.t11 = p[4] * p[4]; q.t21 = p[5] * p[5]; q.t31 = p[6] * p[6];
@@ -499,6 +501,7 @@ int fs_set_lr_params(fs_ctx *ctx, const float p[7])
 {
     if (!ctx || !p) return -1;
     if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));     // kernels in flight still read the tables this call rewrites
     CrfParams &q = ctx->params;
     for (int i = 0; i < 4; ++i) q.lr_coef[i] = p[i];
     q.bias = p[4];
@@ -514,6 +517,7 @@ int fs_set_kernel_size(fs_ctx *ctx, int kernel_size)
     if (!ctx) return -1;
     if (kernel_size < 1 || kernel_size > kMaxRadius) return ctx->fail("kernel_size must be in [1, " + std::to_string(kMaxRadius) + "]");
     if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));     // kernels in flight still read the tables this call rewrites
     ctx->r = kernel_size;
     if (ensure_frame_buffers(ctx)) return -1;
     return ctx->have_params ? build_pos_terms(ctx) : 0;
@@ -522,7 +526,20 @@ int fs_set_kernel_size(fs_ctx *ctx, int kernel_size)
 int fs_set_stream(fs_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return -1;
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    if (set_device(ctx)) return -1;
+    // nothing of this context stays behind on the stream it leaves (a handle the caller has destroyed already
+    // makes this fail, which is as good as drained)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) (void)hipGetLastError();
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);   // a null handle is the legacy default stream
+    return 0;
+}
+
+int fs_use_own_stream(fs_ctx *ctx)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) (void)hipGetLastError();
+    ctx->stream = ctx->own_stream;
     return 0;
 }
 

@@ -41,6 +41,7 @@
 // uses of a similarity value reach L2/HBM once.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "fs_common.h"
 // Timing experiments only (never defined in the product build): -DFS_SKIPMAIN=1 drops the window walk of the
@@ -1198,18 +1199,34 @@ __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *
     }
 }
 
+// Dynamic LDS a kernel instantiation has been allowed so far.  The attribute belongs to (device, function), so
+// the record is kept per device; several contexts (one per GPU, or several host threads) may launch at once.
+struct LdsAllowance {
+    static constexpr int kDevices = 64;
+    std::mutex m;
+    size_t have[kDevices] = {};
+    hipError_t ensure(const void *kern, size_t lds)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> g(m);
+        const bool tracked = dev >= 0 && dev < kDevices;
+        if (tracked && lds <= have[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && tracked) have[dev] = lds;
+        return e;
+    }
+};
+
 template <int R, int PY, int NCH>
 hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, float evidence, int last, hipStream_t st)
 {
-    static size_t attr_lds = 0;
+    static LdsAllowance allowed;
     auto kern = crf_iter_kernel<R, PY, NCH>;
     const size_t lds = (size_t)2 * (ITW + 2 * g.r) * (ITH + 2 * g.r) * sizeof(float4);
     if (lds + sizeof(int) * TILE_REC > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
-    }
+    if (hipError_t e = allowed.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     dim3 grid((g.ow + ITW - 1) / ITW, (g.oh + ITH - 1) / ITH, nframes);
     hipLaunchKernelGGL(kern, grid, dim3(64 * ITH / PY), lds, st, descs, g, weight, evidence, last);
     return hipGetLastError();
@@ -1219,16 +1236,12 @@ template <int R, int TH, int NCH, int MODE, bool UNIFORM = false>
 hipError_t launch_fused_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, const FusedConsts &K, const float4 *wtab,
                           float weight, int first, int last, unsigned *queue, hipStream_t st)
 {
-    static size_t attr_lds = 0;                  // dynamic LDS the kernel has been allowed so far
+    static LdsAllowance allowed;
     auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE, UNIFORM>;
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
     const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8 + 15 * MASK_WORDS + 2 * NCH * 8 + 4);
     if (lds + lds_static > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
-    }
+    if (hipError_t e = allowed.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     const unsigned tiles = (unsigned)((g.Wi + FTW - 1) / FTW) * ((g.Hi + TH - 1) / TH) * nframes;
     // Persistent blocks: as many as the chip holds at once (two per CU by LDS), each pulling tiles from the
     // queue of its XCD until it is empty.  A block that ends and a new one that takes its place cost the CU

@@ -54,9 +54,16 @@ int fs_set_lr_params(fs_ctx *ctx, const float params[7]);
  * (find_surfaces.py:23, 291, 497); default 7, at most 15. */
 int fs_set_kernel_size(fs_ctx *ctx, int kernel_size);
 
-/* Use an existing HIP stream (a hipStream_t passed as void*) instead of the
- * context's own; pass NULL to go back.  Returns the stream in use via fs_stream(). */
+/* Use the caller's HIP stream (a hipStream_t passed as void*) instead of the context's own, so that the
+ * "_dev" entry points are ordered with the caller's other work on that stream.  A NULL handle is HIP's legacy
+ * default stream (what torch.cuda.current_stream().cuda_stream is unless the caller made a stream current).
+ * fs_use_own_stream() goes back to the context's own stream, which is created hipStreamNonBlocking: work on it
+ * is NOT ordered with the default stream, so a caller that stays on the own stream must synchronise on
+ * fs_stream() (or wait on an event recorded there) before it touches the outputs of a "_dev" call or
+ * overwrites its inputs.  Both calls drain the stream they leave.  No counterpart in the reference (TensorFlow
+ * owns its streams). */
 int fs_set_stream(fs_ctx *ctx, void *hip_stream);
+int fs_use_own_stream(fs_ctx *ctx);
 void *fs_stream(fs_ctx *ctx);
 
 /* ---- stage operators: the four models of get_GPU_models() ------------------ */
