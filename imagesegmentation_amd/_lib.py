@@ -34,6 +34,8 @@ SIGNATURES = {
     "fs_normals": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_patches": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_connected_components": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "fs_connected_components_noalloc": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "fs_noalloc_max_pixels": (_c.c_size_t, []),
     "fs_crf_step": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_crf_step_lr": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
@@ -250,6 +252,19 @@ class Context:
         lab, cnt = np.empty((n, self.H, self.W), np.int64), np.empty(n, np.int32)
         self._check(self._lib.fs_connected_components(self._h, n, _ptr(m), int(min_size_exclusive), _ptr(lab), _ptr(cnt)))
         return (lab[0], int(cnt[0])) if single else (lab, cnt)
+
+    def connected_components_noalloc(self, n, d_mask, d_labels, d_num_labels=None, min_size_exclusive=0):
+        """fs_connected_components_noalloc: device pointers (integers); enqueues on the context's stream,
+        allocates nothing, does not synchronise."""
+        self._check(self._lib.fs_connected_components_noalloc(self._h, int(n), d_mask, int(min_size_exclusive), d_labels,
+                                                              d_num_labels))
+
+    def synchronize(self):
+        """Wait for the context's stream through the HIP runtime the library is linked against."""
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipStreamSynchronize.argtypes = [_vp]
+        if hip.hipStreamSynchronize(self.stream()) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
 
     def crf_step(self, unary, Q, f1, f2, f3, val, want_potentials=False):
         unary = _arr(unary, np.float32)

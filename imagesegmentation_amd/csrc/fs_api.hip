@@ -64,6 +64,11 @@ struct fs_ctx {
     size_t N() const { return (size_t)H * W; }
 };
 
+namespace fs {
+CtxView ctx_view(const fs_ctx *ctx) { return CtxView{ctx->device, ctx->H, ctx->W, ctx->stream}; }
+int ctx_fail(fs_ctx *ctx, const std::string &message) { return ctx->fail(message); }
+}  // namespace fs
+
 #define FS_HIP(expr)                                           \
     do {                                                       \
         hipError_t e_ = (expr);                                \
@@ -443,6 +448,9 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
+    // this GPU's copy of the static work space of fs_connected_components_noalloc: looked up here, once per
+    // device, so that the entry point itself does nothing but launch
+    if (hipError_t se = noalloc_scratch_init(device, nullptr); se != hipSuccess) { ctx->fail(se, "static work space"); return bail(0); }
     *out = ctx;
     return 0;
 }

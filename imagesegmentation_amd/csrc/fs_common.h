@@ -6,7 +6,16 @@
 #include <string>
 #include <vector>
 
+struct fs_ctx;
+
 namespace fs {
+
+// what entry points outside fs_api.hip need of a context
+struct CtxView { int device, H, W; hipStream_t stream; };
+CtxView ctx_view(const fs_ctx *ctx);
+int ctx_fail(fs_ctx *ctx, const std::string &message);      // records the message, returns -1
+// work space of fs_connected_components_noalloc (fs_noalloc.hip): address of this GPU's copy, looked up once
+hipError_t noalloc_scratch_init(int device, int32_t **out);
 
 // Grow-only device buffer owned by a context.
 struct DevBuf {

@@ -93,6 +93,18 @@ int fs_patches(fs_ctx *ctx, int n, const float *smoothed, int64_t *patches, int3
 int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_size_exclusive, int64_t *labels,
                             int32_t *num_labels);
 
+/* Connected components without any allocation.  No counterpart in the reference: it exists for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  Same result as fs_connected_components, but every pointer is device memory (d_mask uint8
+ * [n][H][W], d_labels int64 [n][H][W], d_num_labels int32 [n] or NULL), the work is enqueued on the context's
+ * stream without synchronising, and the work space is a static device array of the library (about 14 MiB per
+ * GPU, held until the process ends) instead of the context's buffers: the call uses no hipMalloc / hipFree.
+ * Limit: n * height * width <= fs_noalloc_max_pixels() (1280 * 960); larger calls fail with a message.
+ * All calls on one GPU share that array: calls that overlap on one GPU (other streams, other contexts) race. */
+int fs_connected_components_noalloc(fs_ctx *ctx, int n, const uint8_t *d_mask, int min_size_exclusive,
+                                    int64_t *d_labels, int32_t *d_num_labels);
+size_t fs_noalloc_max_pixels(void);
+
 /* conv_crf_Gauss(...).predict([unary, Q, f1, f2, f3, val], batch_size=1)
  * (find_surfaces.py:291-367, 517-518): one mean-field update on B tiles.
  *   unary [B][h][w][S], Q [B][h+2r][w+2r][S], f1 [B][h+2r][w+2r][3],
