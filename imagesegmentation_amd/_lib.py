@@ -50,6 +50,7 @@ SIGNATURES = {
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "fs_nearest_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_set_timing": (_i, [_vp, _i]),
+    "fs_get_tile_labels": (_i, [_vp, _i, _vp] + [_c.POINTER(_i)] * 4),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
 }
 
@@ -206,6 +207,16 @@ class Context:
         ms, cnt = _d(0), _c.c_int64(0)
         self._check(self._lib.fs_get_timing(self._h, group, ctypes.byref(ms), ctypes.byref(cnt)))
         return ms.value, cnt.value
+
+    def tile_labels(self, n):
+        """Patch labels listed per CRF tile in the last fused call of n frames -> (int32 [n, tiles_y, tiles_x],
+        (tile_h, tile_w))."""
+        tx, ty, tw, th = _i(0), _i(0), _i(0), _i(0)
+        self._check(self._lib.fs_get_tile_labels(self._h, int(n), None, ctypes.byref(tx), ctypes.byref(ty), ctypes.byref(tw),
+                                                 ctypes.byref(th)))
+        out = np.empty((int(n), ty.value, tx.value), np.int32)
+        self._check(self._lib.fs_get_tile_labels(self._h, int(n), _ptr(out), None, None, None, None))
+        return out, (th.value, tw.value)
 
     def _batch(self, a, tail=()):
         a = np.asarray(a)

@@ -577,6 +577,27 @@ int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches)
     return 0;
 }
 
+int fs_get_tile_labels(fs_ctx *ctx, int n, int32_t *listed, int *tiles_x, int *tiles_y, int *tile_w, int *tile_h)
+{
+    if (check_batch(ctx, n)) return -1;
+    const int th = crf_fused_tile_height(ctx->r);
+    if (!th) return ctx->fail("fs_get_tile_labels: no per-tile label lists at this window radius");
+    int tx = 0, ty = 0;
+    crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
+    if (tiles_x) *tiles_x = tx;
+    if (tiles_y) *tiles_y = ty;
+    if (tile_w) *tile_w = 32;
+    if (tile_h) *tile_h = th;
+    if (listed) {
+        // word 0 of every tile record
+        const size_t pitch = crf_tile_rec_ints() * sizeof(int32_t);
+        FS_HIP(hipMemcpy2DAsync(listed, sizeof(int32_t), ctx->tile_recs.p, pitch, sizeof(int32_t), (size_t)n * tx * ty,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
 int fs_smooth_depth(fs_ctx *ctx, int n, const float *depth, float *out)
 {
     if (check_batch(ctx, n)) return -1;

@@ -69,3 +69,55 @@ def make_scene(seed, height=480, width=640, invalid_fraction=0.24):
 def make_batch(seeds, height=480, width=640):
     d, c = zip(*(make_scene(s, height, width) for s in seeds))
     return np.stack(d), np.stack(c)
+
+
+def make_mosaic_scene(seed, height=960, width=1280, n_patches=30, noise_sigma=0.5):
+    """A scene with a prescribed number of smooth surfaces, so that the CRF runs with a chosen channel count
+    S = n_patches + 2: a jittered grid of cells separated by gutters without depth; n_patches of the cells hold
+    one smooth facet each (tilted planes, every third one a shallow cylinder) at well separated distances, the
+    other cells stay empty.  Elliptic holes inside the facets and 0.3 % salt holes bring the invalid fraction to
+    about a quarter.  Depth uint16 (0 = invalid) with Gaussian noise of noise_sigma (the sigma 2 of make_scene breaks
+    every facet into several patches, and the patch count is then no longer the prescribed one), RGB = a base
+    colour per facet + N(0, 8).  Whether a seed really yields n_patches patches is for the user to check (the
+    golden fixtures assert it)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    H, W = height, width
+    gx = int(np.ceil(np.sqrt(n_patches * W / H)))
+    gy = int(np.ceil(n_patches / gx))
+    gutter = 6
+    # jittered cell borders: columns per grid row, rows shared
+    ys = np.linspace(0, H, gy + 1)
+    ys[1:-1] += rng.uniform(-0.12, 0.12, gy - 1) * H / gy
+    ys = np.round(ys).astype(int)
+    depth = np.zeros((H, W), np.float32)
+    rgb = rng.normal(90, 8, (H, W, 3)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    cells = [(j, i) for j in range(gy) for i in range(gx)]
+    keep = {cells[k] for k in rng.permutation(len(cells))[:n_patches]}
+    z_levels = rng.permutation(np.linspace(900, 4400, len(cells)))
+    for k, (j, i) in enumerate(cells):
+        xs = np.linspace(0, W, gx + 1)
+        xs[1:-1] += np.random.Generator(np.random.PCG64(seed * 1000 + j)).uniform(-0.12, 0.12, gx - 1) * W / gx
+        xs = np.round(xs).astype(int)
+        if (j, i) not in keep:
+            continue
+        y0, y1, x0, x1 = ys[j] + gutter, ys[j + 1] - gutter, xs[i] + gutter, xs[i + 1] - gutter
+        yc, xc = (y0 + y1) / 2, (x0 + x1) / 2
+        sl = np.s_[y0:y1, x0:x1]
+        z = z_levels[k] + rng.uniform(-0.8, 0.8) * (xx[sl] - xc) + rng.uniform(-0.8, 0.8) * (yy[sl] - yc)
+        if k % 3 == 2:      # shallow cylinder: sagitta of a few centimetres across the cell
+            z = z - rng.uniform(20, 60) * (1 - ((xx[sl] - xc) / ((x1 - x0) / 2)) ** 2)
+        depth[sl] = z
+        rgb[sl] = rng.integers(20, 236, 3).astype(np.float32) + rng.normal(0, 8, z.shape + (3,)).astype(np.float32)
+        # an elliptic hole strictly inside the cell (cannot split the facet)
+        hy, hx = rng.uniform(0.1, 0.22) * (y1 - y0), rng.uniform(0.1, 0.22) * (x1 - x0)
+        cy, cx = yc + rng.uniform(-0.15, 0.15) * (y1 - y0), xc + rng.uniform(-0.15, 0.15) * (x1 - x0)
+        hole = ((yy[sl] - cy) / hy) ** 2 + ((xx[sl] - cx) / hx) ** 2 < 1
+        depth[sl][hole] = 0
+    valid = depth > 0
+    if noise_sigma > 0:
+        depth = depth + rng.normal(0, noise_sigma, (H, W)).astype(np.float32)
+    depth = np.clip(depth, 500, 5000)
+    depth_u16 = np.round(depth).astype(np.uint16)
+    depth_u16[~valid | (rng.random((H, W)) < 0.003)] = 0
+    return depth_u16, np.clip(np.round(rgb), 0, 255).astype(np.uint8)

@@ -226,6 +226,12 @@ int fs_nearest_points(fs_ctx *ctx, int groups, const float *points, const int32_
  * Groups: 0 stencils, 1 connected components, 2 crf similarity, 3 crf init,
  * 4 crf iteration (one launch = one mean-field update of one frame). */
 int fs_set_timing(fs_ctx *ctx, int group_mask);
+/* Work the CRF update actually executed in the last fs_find_surfaces_batch(_dev) / fs_apply_crf call of n frames
+ * (no more than 16 for the host-pointer call, which works in chunks): listed (may be NULL) int32
+ * [n][tiles_y][tiles_x] receives the number of patch labels each tile lists (its update carries those labels plus
+ * label 0, the "unassigned" label and one representative of all others instead of the frame's S channels);
+ * the tile grid and tile size come back through the other pointers.  Host pointers; synchronises. */
+int fs_get_tile_labels(fs_ctx *ctx, int n, int32_t *listed, int *tiles_x, int *tiles_y, int *tile_w, int *tile_h);
 int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus

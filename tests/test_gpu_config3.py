@@ -1,0 +1,43 @@
+"""Large frames with larger CRF windows: seeded synthetic 1280x960 frames with a prescribed number of label
+channels S in {16, 32, 64} and window radii 7, 10 and 15 (the kernel_size argument of conv_crf_Gauss,
+find_surfaces.py:291-293, 312), through the C ABI, against the oracle results committed in
+tests/golden/synth1280.npz (tests/golden/make_golden_1280.py: the C oracle needs minutes for these frames, so it
+ran where the fixtures were made).  Patch labels and depth edges bit-exact; CRF labels may differ from the oracle's
+only where its two largest label probabilities lie within 1e-5 relative, and at least 99.9 % must be equal."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth1280.npz")
+H, W = 960, 1280
+
+
+def _cases():
+    g = np.load(GOLDEN)
+    return [tuple(int(v) for v in row) for row in g["cases"]]
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_synthetic_1280x960(k):
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_mosaic_scene
+    g = np.load(GOLDEN)
+    seed, n_patches, r = _cases()[k]
+    d, c = make_mosaic_scene(seed, H, W, n_patches)
+    assert zlib.crc32(d.tobytes()) == g[f"crc_depth_{k}"], "the generator no longer reproduces the fixture's frame"
+    with Context(H, W, max_batch=1, kernel_size=r) as ctx:
+        got = ctx.find_surfaces_batch(d, c)
+    assert got["num_surfaces"] == g[f"num_surfaces_{k}"] == n_patches + 1
+    assert zlib.crc32(np.ascontiguousarray(got["patches"].astype(np.int32)).tobytes()) == g[f"crc_patches_{k}"]
+    assert zlib.crc32(np.ascontiguousarray(got["depth_edges"].astype(np.int8)).tobytes()) == g[f"crc_edges_{k}"]
+    dis = got["surfaces"] != g[f"surfaces_{k}"]
+    tie = np.unpackbits(g[f"near_tie_{k}"])[:dis.size].reshape(dis.shape).astype(bool)
+    agreement = 1.0 - dis.mean()
+    print(f"S = {n_patches + 2}, r = {r}: label agreement {100 * agreement:.4f} %, {int(dis.sum())} differing pixels")
+    assert not (dis & ~tie).any(), f"{int((dis & ~tie).sum())} label differences that are not numerical ties"
+    assert agreement >= 0.999, agreement
+    assert (got["surfaces"][d == 0] == 0).all()
