@@ -1,0 +1,183 @@
+// Pieces shared by the CRF update kernels of k_crf.hip and the fused-update instance files.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+
+#include "fs_common.h"
+// Timing experiments only (never defined in the product build): -DFS_SKIPMAIN=1 drops the window walk of the
+// fused update, -DFS_SKIPQ=1 the staging of Q, -DFS_SKIPFIN=1 the epilogue.  Builds with parts switched off,
+// run under the SQ counters (tools/pmc_variant.sh), tell how the vector instructions split over the phases.
+#ifndef FS_SKIPQ
+#define FS_SKIPQ 0
+#endif
+#ifndef FS_SKIPFIN
+#define FS_SKIPFIN 0
+#endif
+#ifndef FS_SKIPMAIN
+#define FS_SKIPMAIN 0
+#endif
+
+namespace fs {
+
+// constants of the fused update: exponent factors of the relative depth difference for the three Gaussian kernels,
+// the evidence of the "unassigned" label; uw: -log2 of the window's common (w1', w2', w3') when uniform
+struct FusedConsts { float K1, K2, K3, evidence; float uw[4]; };
+// one launch of the fused update over `nframes` frames (descs: device array)
+struct FusedLaunch {
+    const CrfFrameDesc *descs;
+    int nframes;
+    CrfGeom g;
+    FusedConsts K;
+    const float4 *wtab;      // per-offset weights [(2r+1)^2] = (w1', w2', w3', bias), zeros at the centre
+    float weight;
+    int first, last;
+    unsigned *queue;
+    hipStream_t st;
+};
+// Instance files (k_crf_fused_*.hip): each compiles the kernel variants it names and returns
+// hipErrorInvalidValue for a combination it does not carry.
+//   variant: 0 = Gaussian similarity, window constants uniform; 1 = Gaussian, per-offset weight table;
+//            2 = logistic-regression similarity
+hipError_t launch_fused_r7_uniform(int channel_class, const FusedLaunch &L);      // static tile + halo in LDS, r = 7
+hipError_t launch_roll_uniform(int channel_class, const FusedLaunch &L);          // rolling window, variant 0, any radius
+hipError_t launch_roll_table(int variant, int channel_class, const FusedLaunch &L);   // rolling window, variants 1 and 2
+
+constexpr int FTW = 32;                       // tile width of the fused kernel
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));      // packed pair: arithmetic lowers to v_pk_*_f32
+typedef __attribute__((address_space(1))) float gfloat;   // pointer known to be global: saddr + 32-bit offset loads
+
+// per-tile record of crf_tile_active_kernel (TILE_REC ints): [0] = count A of listed labels,
+// [REC_MASK .. REC_MASK+MASK_WORDS) = bit mask, [REC_LAB .. REC_LAB+A) = the labels, ascending
+constexpr int MASK_WORDS = kMaxLabels / 32;
+constexpr int REC_MASK = 8, REC_LAB = REC_MASK + MASK_WORDS;
+constexpr int TILE_REC = REC_LAB + kMaxLabels;
+
+// Dynamic LDS a kernel instantiation has been allowed so far.  The attribute belongs to (device, function), so
+// the record is kept per device; several contexts (one per GPU, or several host threads) may launch at once.
+struct LdsAllowance {
+    static constexpr int kDevices = 64;
+    std::mutex m;
+    size_t have[kDevices] = {};
+    hipError_t ensure(const void *kern, size_t lds)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> g(m);
+        const bool tracked = dev >= 0 && dev < kDevices;
+        if (tracked && lds <= have[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && tracked) have[dev] = lds;
+        return e;
+    }
+};
+
+// Potts compatibility, softmax and overrides of the fused update for the two vertically adjacent pixels a lane owns
+// (compact planes, synthesised unary, no potentials output).  m[c] = messages of channel slot c as a packed pair
+// (pixel 0, pixel 1), so the arithmetic is v_pk_*_f32 like the window walk.  The work follows the tile's channel
+// count: slots are visited in groups of four behind one uniform test per group, and what depends on a slot's role
+// comes from s_tab[c] = (multiplicity, evidence, unary, -): multiplicity 1 for a listed label, n_rest for the
+// representative, 0 for an unused slot of the last group; evidence of the constant "unassigned" input at the last
+// channel (find_surfaces.py:356-357, 451-452); unary potential of the slot's label at a pixel that does not belong to
+// it: 10 for label 0, 1 otherwise (:459-472), +inf for an unused slot (probability 0).
+template <int NC>
+__device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_list, const float4 *s_tab, const CrfFrameDesc &d, int S,
+                                                    size_t No, const unsigned (&p)[2], const int (&own)[2], const bool (&ok)[2],
+                                                    const bool (&valid)[2], float weight, int last)
+{
+    static_assert(NC % 4 == 0, "channel slots come in groups of four");
+    const int CE = s_list[0];
+    const float pv = (float)(1.0 / (double)(S - 1));
+    // a pixel's own patch label as a key no slot matches when the pixel lies in no patch
+    const int key0 = own[0] != 0 ? own[0] : -1, key1 = own[1] != 0 ? own[1] : -1;
+    // total over all S labels (the representative counts n_rest times), compensated so that
+    // compatibility[l] = total - msg[l] keeps full relative accuracy
+    f2 tot = f2{0.0f, 0.0f}, tot_lo = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                const float4 role = s_tab[c];
+                m[c] = m[c] + f2{role.y, role.y};
+                const f2 term = m[c] * f2{role.x, role.x};
+                const f2 t = tot + term;
+                const f2 bp = t - tot;
+                tot_lo += (tot - (t - bp)) + (term - bp);
+                tot = t;
+            }
+        }
+    }
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                const int lab = s_list[REC_LAB + c];
+                const float base = s_tab[c].z;
+                const f2 comp = (tot - m[c]) + tot_lo;             // Potts: sum of the other labels' messages (:297-298, 360)
+                const f2 un = f2{lab == key0 ? 0.0f : base, lab == key1 ? 0.0f : base};   // :459-472
+                m[c] = -(un + f2{weight, weight} * comp);          // :361
+                mx0 = fmaxf(mx0, m[c].x);
+                mx1 = fmaxf(mx1, m[c].y);
+            }
+        }
+    }
+    if (last) {
+        // Only the label is wanted (:531-532).  The softmax is monotone, so its first maximum is the first maximum of
+        // its argument, except where two arguments differ by so little that their exponentials round to the same
+        // float: such labels are numerically tied and the choice between them carries no information.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!ok[i]) continue;
+            int best = 0;
+            float bestv = -INFINITY;
+            if (valid[i]) {                                              // Q[depth == 0] = 0: argmax of zeros is label 0
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (c < CE) {
+                        const int lab = s_list[REC_LAB + c];
+                        const float v = i == 0 ? m[c].x : m[c].y;
+                        if (v > bestv || (v == bestv && lab < best)) { bestv = v; best = lab; }
+                    }
+                }
+            }
+            d.surfaces[p[i]] = best == S - 1 ? 0 : best;
+        }
+        return;
+    }
+    f2 den = f2{0.0f, 0.0f};
+    const f2 mx = f2{mx0, mx1};
+#pragma unroll
+    for (int g = 0; g < NC / 4; ++g) {
+        if (g * 4 < CE) {
+#pragma unroll
+            for (int c = g * 4; c < g * 4 + 4; ++c) {
+                const f2 a = (m[c] - mx) * f2{1.44269504088896341f, 1.44269504088896341f};
+                m[c] = f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};      // softmax(-add), :363
+                const float mult = s_tab[c].x;
+                den = __builtin_elementwise_fma(m[c], f2{mult, mult}, den);
+            }
+        }
+    }
+    const f2 inv_den = f2{1.0f / den.x, 1.0f / den.y};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            const int lab = s_list[REC_LAB + c];
+            const f2 q = m[c] * inv_den;
+            const float ov = lab == 0 ? 0.0f : pv;                       // Q[depth == 0] = prob, :520-525
+            if (ok[0]) d.Qout[(size_t)lab * No + p[0]] = valid[0] ? q.x : ov;
+            if (ok[1]) d.Qout[(size_t)lab * No + p[1]] = valid[1] ? q.y : ov;
+        }
+    }
+}
+
+}  // namespace
+
+}  // namespace fs
