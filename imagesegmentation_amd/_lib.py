@@ -44,7 +44,9 @@ SIGNATURES = {
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
     "fs_apply_crf": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fs_surface_stats": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
+    "fs_surface_stats_rgb": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 16),
     "fs_surface_stats_dev": (_i, [_vp, _i] + [_vp] * 7 + [_i] + [_vp] * 15),
+    "fs_surface_stats_batch_dev": (_i, [_vp, _i] + [_vp] * 9 + [_i] + [_vp] * 16),
     "fs_chi_squared_distances": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_chi_squared_distances_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -343,13 +345,14 @@ class Context:
                                                          d_patches, d_edges, d_surfaces, _ptr(ns)))
         return ns
 
-    def surface_stats(self, surfaces, patches, depth_edges, points_3d, angles, lab, texture, num_surfaces):
-        """fs_surface_stats for one frame -> dict of arrays (see include/fs_hip.h)."""
+    def surface_stats(self, surfaces, patches, depth_edges, points_3d, angles, lab, texture, num_surfaces, rgb=None):
+        """fs_surface_stats for one frame -> dict of arrays (see include/fs_hip.h).  With lab=None and rgb given
+        (uint8 [H,W,3]) the colour conversion runs on the device (fs_surface_stats_rgb) and the dict also holds "lab".
+        The large outputs live in page-locked memory (their downloads are DMA transfers)."""
         S, H, W = int(num_surfaces), self.H, self.W
         surfaces, patches = _arr(surfaces, np.int64, (H, W)), _arr(patches, np.int64, (H, W))
         depth_edges = _arr(depth_edges, np.int32, (H, W))
         points_3d, angles = _arr(points_3d, np.float32, (H, W, 3)), _arr(angles, np.float32, (H, W, 2))
-        lab = _arr(lab, np.float64, (H, W, 3))
         T = 256
         if texture is not None:
             texture = _arr(texture, np.float32)
@@ -357,18 +360,24 @@ class Context:
                 raise ValueError(f"texture must be [{H // 4},{W // 4},T], got {texture.shape}")
             T = texture.shape[2]
         out = {
-            "surfaces": np.empty((H, W), np.int64), "patch_point_offsets": np.empty(S + 1, np.int32),
-            "patch_points": np.empty((H * W, 2), np.float32), "avg_pos": np.empty((S, 2)), "counts": np.empty((S, 1)),
+            "surfaces": pinned_empty((H, W), np.int64), "patch_point_offsets": np.empty(S + 1, np.int32),
+            "patch_points": pinned_empty((H * W, 2), np.float32), "avg_pos": np.empty((S, 2)), "counts": np.empty((S, 1)),
             "centroids": np.empty((S, 3), np.float32), "centroid_indices": np.empty((S, 2), np.int32),
-            "hist_color": np.empty((256, 256, S)), "hist_angle": np.empty((40, 40, S)), "hist_texture": np.empty((S, T)),
+            "hist_color": pinned_empty((256, 256, S), np.float64), "hist_angle": np.empty((40, 40, S)), "hist_texture": np.empty((S, T)),
             "avg_angles": np.empty((S, 2)), "neighbor_counts": np.empty((S, S)), "border_centers": np.empty((S, S, 2)),
-            "norm": np.empty((H, W), np.float32), "depth_extend": np.empty((S, 4, 2), np.float32),
+            "norm": pinned_empty((H, W), np.float32), "depth_extend": np.empty((S, 4, 2), np.float32),
         }
-        order = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
-                 "hist_color", "hist_angle", "hist_texture", "avg_angles", "neighbor_counts", "border_centers", "norm",
-                 "depth_extend")
-        self._check(self._lib.fs_surface_stats(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
-                                               _ptr(angles), _ptr(lab), _ptr(texture), T, *(_ptr(out[k]) for k in order)))
+        if lab is not None:
+            lab = _arr(lab, np.float64, (H, W, 3))
+            self._check(self._lib.fs_surface_stats(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
+                                                   _ptr(angles), _ptr(lab), _ptr(texture), T, *(_ptr(out[k]) for k in self.STATS_OUTPUTS)))
+        else:
+            rgb = _arr(rgb, np.uint8, (H, W, 3))
+            lab_out = pinned_empty((H, W, 3), np.float64)
+            self._check(self._lib.fs_surface_stats_rgb(self._h, S, _ptr(surfaces), _ptr(patches), _ptr(depth_edges), _ptr(points_3d),
+                                                       _ptr(angles), _ptr(rgb), _ptr(texture), T, _ptr(lab_out),
+                                                       *(_ptr(out[k]) for k in self.STATS_OUTPUTS)))
+            out["lab"] = lab_out
         return out
 
     STATS_OUTPUTS = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
@@ -385,6 +394,27 @@ class Context:
         self._check(self._lib.fs_surface_stats_dev(self._h, int(num_surfaces), d_surfaces, d_patches, d_depth_edges, d_points_3d,
                                                    d_angles, d_lab, d_texture, int(texture_dim),
                                                    *(d_out.get(k) for k in self.STATS_OUTPUTS)))
+
+    @staticmethod
+    def stats_output_elements(H, W, S, T=256):
+        """Elements of each output of the statistics stage for one frame with S surfaces, by the names of
+        STATS_OUTPUTS (the layout fs_surface_stats_batch_dev concatenates frame after frame)."""
+        N = H * W
+        return {"surfaces": N, "patch_point_offsets": S + 1, "patch_points": 2 * N, "avg_pos": 2 * S, "counts": S, "centroids": 3 * S,
+                "centroid_indices": 2 * S, "hist_color": 65536 * S, "hist_angle": 1600 * S, "hist_texture": S * T, "avg_angles": 2 * S,
+                "neighbor_counts": S * S, "border_centers": 2 * S * S, "norm": N, "depth_extend": 8 * S}
+
+    def surface_stats_batch_dev(self, num_surfaces, d_surfaces, d_patches, d_depth_edges, d_points_3d, d_angles, d_lab=None, d_rgb=None,
+                                d_texture=None, texture_dim=256, d_lab_out=None, **d_out):
+        """fs_surface_stats_batch_dev: device pointers (integers) of arrays that hold the frames back to back;
+        num_surfaces: one entry per frame.  Outputs by the names of STATS_OUTPUTS, missing ones are not produced."""
+        unknown = set(d_out) - set(self.STATS_OUTPUTS)
+        if unknown:
+            raise TypeError(f"unknown outputs {sorted(unknown)}")
+        ns = np.ascontiguousarray(num_surfaces, np.int32).reshape(-1)
+        self._check(self._lib.fs_surface_stats_batch_dev(self._h, len(ns), _ptr(ns), d_surfaces, d_patches, d_depth_edges, d_points_3d,
+                                                         d_angles, d_lab, d_rgb, d_texture, int(texture_dim), d_lab_out,
+                                                         *(d_out.get(k) for k in self.STATS_OUTPUTS)))
 
     def chi_squared_distances(self, hist, pool_size=(1, 1), strides=(1, 1)):
         hist = _arr(hist, np.float64)

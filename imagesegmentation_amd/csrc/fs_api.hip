@@ -44,7 +44,8 @@ struct fs_ctx {
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
     // per-surface statistics (one frame in flight)
-    DevBuf st_in, st_work, st_sort, st_scratch, st_out, st_pool;
+    DevBuf st_in, st_work, st_scratch, st_out, st_pool, st_descs, st_lin, st_lab;
+    std::vector<StatsFrame> st_descs_host;
 
     // timing
     unsigned timing = 0;   // bit g set: record events around kernel group g
@@ -463,7 +464,7 @@ void fs_destroy(fs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
-                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_sort,
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin, &ctx->st_lab,
                       &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
                       &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();
@@ -912,63 +913,125 @@ namespace {
 
 constexpr int kStatsOutputs = 15;
 
-// Shared body of fs_surface_stats and fs_surface_stats_dev.  `in` and the non-null entries of user_out are device
-// pointers; outputs the caller did not ask for go to the context's staging buffer.  od[i] receives the device address
-// output i was written to, out_sizes[i] its size in bytes.  Synchronises once to read the error flag.
-int surface_stats_core(fs_ctx *ctx, const char *who, int S, int T, const StatsIn &in, void *const user_out[kStatsOutputs],
-                       char *od[kStatsOutputs], size_t out_sizes[kStatsOutputs])
+// bytes of output k for a frame of N pixels with S surfaces and T texture components
+void stats_output_sizes(size_t N, size_t S, size_t T, size_t sizes[kStatsOutputs])
+{
+    const size_t v[kStatsOutputs] = {N * 8, (S + 1) * 4, N * 8, S * 16, S * 8, S * 12, S * 8, 65536 * S * 8, 1600 * S * 8, S * T * 8, S * 16,
+                                     S * S * 8, S * S * 16, N * 4, S * 32};
+    for (int k = 0; k < kStatsOutputs; ++k) sizes[k] = v[k];
+}
+
+struct StatsInputs {                 // device pointers, frames back to back
+    const int64_t *surfaces, *patches;
+    const int32_t *edges;
+    const float *points_3d, *angles;
+    const double *lab;               // or null when rgb is given
+    const uint8_t *rgb;
+    const float *texture;            // or null
+    double *lab_out;                 // or null: where to leave the converted colours
+};
+
+// Shared body of the statistics entry points: n frames, frame i with S[i] surfaces.  `in` and the non-null entries of
+// user_out are device pointers (arrays of all frames back to back, frame i's part sized by S[i]); outputs the caller
+// did not ask for go to the context's staging buffer.  od[k] receives the device address of output k, out_bytes[k] its
+// total size.  Synchronises once to read the error flag.
+int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, int T, const StatsInputs &in, void *const user_out[kStatsOutputs],
+                       char *od[kStatsOutputs], size_t out_bytes[kStatsOutputs])
 {
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
-    auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
-    FS_HIP(ctx->st_work.ensure(8 * up8(N * 4)));
-    StatsWork w{};
-    {
-        char *p = ctx->st_work.as<char>();
-        void **slots[8] = {(void **)&w.surf32, (void **)&w.pat32, (void **)&w.parent, (void **)&w.count,
-                           (void **)&w.sort_key, (void **)&w.sort_key_out, (void **)&w.sort_val, (void **)&w.sort_val_out};
-        for (auto *sl : slots) { *sl = p; p += up8(N * 4); }
+    const int nblk = stats_blocks_per_frame(H, W);
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    // sizes
+    std::vector<size_t> off((size_t)kStatsOutputs * (n + 1), 0);           // off[k * (n+1) + i]: byte offset of frame i in output k
+    StatsScratchSizes tot{0, 0, 0, 0};
+    std::vector<StatsScratchSizes> ss(n);
+    for (int i = 0; i < n; ++i) {
+        size_t sz[kStatsOutputs];
+        stats_output_sizes(N, (size_t)S[i], (size_t)T, sz);
+        for (int k = 0; k < kStatsOutputs; ++k) off[(size_t)k * (n + 1) + i + 1] = off[(size_t)k * (n + 1) + i] + sz[k];
+        ss[i] = stats_scratch_sizes(S[i], T, nblk);
+        tot.zero += ss[i].zero; tot.ones += ss[i].ones; tot.ext += ss[i].ext; tot.plain += ss[i].plain;
     }
-    w.sort_temp_bytes = stats_sort_temp_bytes((int)N);
-    FS_HIP(ctx->st_sort.ensure(w.sort_temp_bytes));
-    w.sort_temp = ctx->st_sort.p;
-    FS_HIP(ctx->st_scratch.ensure(stats_work_bytes(S, T) + 256));
-    w.scratch = ctx->st_scratch.p;
-    const size_t SS = (size_t)S * S;
-    const size_t sizes[kStatsOutputs] = {N * 8, (size_t)(S + 1) * 4, N * 8, (size_t)S * 16, (size_t)S * 8, (size_t)S * 12, (size_t)S * 8,
-                                         (size_t)65536 * S * 8, (size_t)1600 * S * 8, (size_t)S * T * 8, (size_t)S * 16, SS * 8, SS * 16,
-                                         N * 4, (size_t)S * 32};
-    size_t staged = 256;                                      // the error flag
-    for (int i = 0; i < kStatsOutputs; ++i) {
-        out_sizes[i] = sizes[i];
-        if (!user_out[i]) staged += up8(sizes[i]);
+    size_t staged = 256;                                                    // the error flag
+    for (int k = 0; k < kStatsOutputs; ++k) {
+        out_bytes[k] = off[(size_t)k * (n + 1) + n];
+        if (!user_out[k]) staged += up(out_bytes[k]);
     }
     FS_HIP(ctx->st_out.ensure(staged));
+    FS_HIP(ctx->st_work.ensure(4 * up((size_t)n * N * 4)));
+    FS_HIP(ctx->st_scratch.ensure(up(tot.zero) + up(tot.ones) + up(tot.ext) + up(tot.plain)));
+    FS_HIP(ctx->st_descs.ensure((size_t)n * sizeof(StatsFrame)));
+    if (in.rgb) {
+        if (!ctx->st_lin.p) {
+            // sRGB byte -> linear light, the first step of the colour conversion (utils.rgb_to_Lab)
+            double lin[256];
+            for (int v = 0; v < 256; ++v) {
+                const double c = (double)v / 255.0;
+                lin[v] = c > 0.04045 ? std::pow((c + 0.055) / 1.055, 2.4) : c / 12.92;
+            }
+            FS_HIP(ctx->st_lin.ensure(sizeof(lin)));
+            FS_HIP(hipMemcpy(ctx->st_lin.p, lin, sizeof(lin), hipMemcpyHostToDevice));
+        }
+        if (!in.lab_out) FS_HIP(ctx->st_lab.ensure((size_t)n * N * 24));
+    }
     char *p = ctx->st_out.as<char>();
     int *d_err = reinterpret_cast<int *>(p);
     p += 256;
-    for (int i = 0; i < kStatsOutputs; ++i) {
-        if (user_out[i]) od[i] = static_cast<char *>(user_out[i]);
-        else { od[i] = p; p += up8(sizes[i]); }
+    for (int k = 0; k < kStatsOutputs; ++k) {
+        if (user_out[k]) od[k] = static_cast<char *>(user_out[k]);
+        else { od[k] = p; p += up(out_bytes[k]); }
     }
-    StatsOut out{};
-    out.surfaces = reinterpret_cast<int64_t *>(od[0]);
-    out.patch_point_offsets = reinterpret_cast<int32_t *>(od[1]);
-    out.patch_points = reinterpret_cast<float *>(od[2]);
-    out.avg_pos = reinterpret_cast<double *>(od[3]);
-    out.counts = reinterpret_cast<double *>(od[4]);
-    out.centroids = reinterpret_cast<float *>(od[5]);
-    out.centroid_idx = reinterpret_cast<int32_t *>(od[6]);
-    out.hist_color = reinterpret_cast<double *>(od[7]);
-    out.hist_angle = reinterpret_cast<double *>(od[8]);
-    out.hist_texture = reinterpret_cast<double *>(od[9]);
-    out.avg_angles = reinterpret_cast<double *>(od[10]);
-    out.neighbors = reinterpret_cast<double *>(od[11]);
-    out.border_centers = reinterpret_cast<double *>(od[12]);
-    out.norm = reinterpret_cast<float *>(od[13]);
-    out.depth_extend = reinterpret_cast<float *>(od[14]);
-    out.err = d_err;
-    hipError_t e = launch_surface_stats(in, w, out, H, W, S, T, ctx->stream);
+    StatsBatchWork w{};
+    {
+        char *q = ctx->st_work.as<char>();
+        void **slots[4] = {(void **)&w.surf32, (void **)&w.pat32, (void **)&w.parent, (void **)&w.count};
+        for (auto *sl : slots) { *sl = q; q += up((size_t)n * N * 4); }
+    }
+    char *zero = ctx->st_scratch.as<char>(), *ones = zero + up(tot.zero), *ext = ones + up(tot.ones), *plain = ext + up(tot.ext);
+    w.lin = ctx->st_lin.as<double>();
+    w.ext_all = reinterpret_cast<uint32_t *>(ext);
+    w.ext_words = tot.ext / 4;
+    w.err = d_err;
+    FS_HIP(hipMemsetAsync(zero, 0, tot.zero, ctx->stream));
+    FS_HIP(hipMemsetAsync(ones, 0xff, tot.ones, ctx->stream));
+    FS_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    std::vector<StatsFrame> &fh = ctx->st_descs_host;
+    fh.assign(n, StatsFrame{});
+    double *lab_work = in.rgb ? (in.lab_out ? in.lab_out : ctx->st_lab.as<double>()) : nullptr;
+    for (int i = 0; i < n; ++i) {
+        StatsFrame &f = fh[i];
+        f.S = S[i];
+        f.surfaces = in.surfaces + (size_t)i * N;
+        f.patches = in.patches + (size_t)i * N;
+        f.edges = in.edges + (size_t)i * N;
+        f.points_3d = in.points_3d + (size_t)i * N * 3;
+        f.angles = in.angles + (size_t)i * N * 2;
+        f.rgb = in.rgb ? in.rgb + (size_t)i * N * 3 : nullptr;
+        f.lab_work = lab_work ? lab_work + (size_t)i * N * 3 : nullptr;
+        f.lab = in.rgb ? f.lab_work : in.lab + (size_t)i * N * 3;
+        f.texture = in.texture ? in.texture + (size_t)i * (N / 16) * T : nullptr;
+        stats_carve_scratch(f, T, nblk, zero, ones, ext, plain);
+        zero += ss[i].zero; ones += ss[i].ones; ext += ss[i].ext; plain += ss[i].plain;
+        auto at = [&](int k) { return od[k] + off[(size_t)k * (n + 1) + i]; };
+        f.surfaces_out = reinterpret_cast<int64_t *>(at(0));
+        f.offsets = reinterpret_cast<int32_t *>(at(1));
+        f.patch_points = reinterpret_cast<float *>(at(2));
+        f.avg_pos = reinterpret_cast<double *>(at(3));
+        f.counts = reinterpret_cast<double *>(at(4));
+        f.centroids = reinterpret_cast<float *>(at(5));
+        f.centroid_idx = reinterpret_cast<int32_t *>(at(6));
+        f.hist_color_out = reinterpret_cast<double *>(at(7));
+        f.hist_angle_out = reinterpret_cast<double *>(at(8));
+        f.hist_texture_out = reinterpret_cast<double *>(at(9));
+        f.avg_angles = reinterpret_cast<double *>(at(10));
+        f.neighbors = reinterpret_cast<double *>(at(11));
+        f.border_centers = reinterpret_cast<double *>(at(12));
+        f.norm = reinterpret_cast<float *>(at(13));
+        f.depth_extend = reinterpret_cast<float *>(at(14));
+    }
+    FS_HIP(hipMemcpyAsync(ctx->st_descs.p, fh.data(), (size_t)n * sizeof(StatsFrame), hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_surface_stats_batch(ctx->st_descs.as<StatsFrame>(), fh.data(), n, w, H, W, T, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, (std::string(who) + ": launch").c_str());
     int err = 0;
     FS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -979,12 +1042,65 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int S, int T, const StatsIn
     return 0;
 }
 
-int stats_check_args(fs_ctx *ctx, const char *who, int S, int T, bool has_texture, bool inputs_ok)
+int stats_check_args(fs_ctx *ctx, const char *who, int n, const int32_t *S, int T, bool has_texture, bool inputs_ok)
 {
-    if (S < 1 || S > kMaxLabels) return ctx->fail(std::string(who) + ": num_surfaces outside [1, " + std::to_string(kMaxLabels) + "]");
+    if (n < 1 || !S) return ctx->fail(std::string(who) + ": need at least one frame and its num_surfaces");
+    for (int i = 0; i < n; ++i)
+        if (S[i] < 1 || S[i] > kMaxLabels) return ctx->fail(std::string(who) + ": num_surfaces outside [1, " + std::to_string(kMaxLabels) + "]");
     if (T < 1 || T > 4096) return ctx->fail(std::string(who) + ": texture_dim outside [1, 4096]");
     if (has_texture && (ctx->H % 4 || ctx->W % 4)) return ctx->fail(std::string(who) + ": texture input needs frame sides divisible by 4");
     if (!inputs_ok) return ctx->fail(std::string(who) + ": null input");
+    return 0;
+}
+
+}  // namespace
+
+namespace {
+
+// host-pointer statistics of one frame: colours as lab (float64) or as rgb (uint8, converted on the device)
+int surface_stats_host(fs_ctx *ctx, const char *who, int num_surfaces, const int64_t *surfaces, const int64_t *patches,
+                       const int32_t *depth_edges, const float *points_3d, const float *angles, const double *lab, const uint8_t *rgb,
+                       const float *texture, int texture_dim, double *lab_out, void *const host_out[kStatsOutputs])
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    const int32_t S = num_surfaces;
+    const int T = texture_dim;
+    if (stats_check_args(ctx, who, 1, &S, T, texture != nullptr, surfaces && patches && depth_edges && points_3d && angles && (lab || rgb)))
+        return -1;
+    const size_t N = ctx->N();
+    auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t in_sizes[8] = {N * 8, N * 8, N * 4, N * 12, N * 8, lab ? N * 24 : 0, lab ? 0 : N * 3, texture ? N / 16 * T * 4 : 0};
+    const void *in_host[8] = {surfaces, patches, depth_edges, points_3d, angles, lab, rgb, texture};
+    size_t in_total = 0;
+    for (size_t b : in_sizes) in_total += up8(b);
+    if (!lab && lab_out) in_total += up8(N * 24);
+    FS_HIP(ctx->st_in.ensure(in_total));
+    char *in_dev[8];
+    char *p = ctx->st_in.as<char>();
+    for (int i = 0; i < 8; ++i) {
+        in_dev[i] = p;
+        if (in_sizes[i]) FS_HIP(hipMemcpyAsync(p, in_host[i], in_sizes[i], hipMemcpyHostToDevice, ctx->stream));
+        p += up8(in_sizes[i]);
+    }
+    StatsInputs in{};
+    in.surfaces = reinterpret_cast<const int64_t *>(in_dev[0]);
+    in.patches = reinterpret_cast<const int64_t *>(in_dev[1]);
+    in.edges = reinterpret_cast<const int32_t *>(in_dev[2]);
+    in.points_3d = reinterpret_cast<const float *>(in_dev[3]);
+    in.angles = reinterpret_cast<const float *>(in_dev[4]);
+    in.lab = lab ? reinterpret_cast<const double *>(in_dev[5]) : nullptr;
+    in.rgb = lab ? nullptr : reinterpret_cast<const uint8_t *>(in_dev[6]);
+    in.texture = texture ? reinterpret_cast<const float *>(in_dev[7]) : nullptr;
+    in.lab_out = (!lab && lab_out) ? reinterpret_cast<double *>(p) : nullptr;
+    void *const none[kStatsOutputs] = {};
+    char *od[kStatsOutputs];
+    size_t out_sizes[kStatsOutputs];
+    if (surface_stats_core(ctx, who, 1, &S, T, in, none, od, out_sizes)) return -1;
+    for (int i = 0; i < kStatsOutputs; ++i)
+        if (host_out[i]) FS_HIP(hipMemcpyAsync(host_out[i], od[i], out_sizes[i], hipMemcpyDeviceToHost, ctx->stream));
+    if (in.lab_out) FS_HIP(hipMemcpyAsync(lab_out, in.lab_out, N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -996,46 +1112,25 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
                      float *centroids, int32_t *centroid_indices, double *hist_color, double *hist_angle, double *hist_texture,
                      double *avg_angles, double *neighbors, double *border_centers, float *norm, float *depth_extend)
 {
-    if (!ctx) return -1;
-    if (set_device(ctx)) return -1;
-    const int S = num_surfaces, T = texture_dim;
-    if (stats_check_args(ctx, "fs_surface_stats", S, T, texture != nullptr,
-                         surfaces && patches && depth_edges && points_3d && angles && lab))
-        return -1;
-    const size_t N = ctx->N();
-    auto up8 = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t in_sizes[7] = {N * 8, N * 8, N * 4, N * 12, N * 8, N * 24, texture ? N / 16 * T * 4 : 0};
-    const void *in_host[7] = {surfaces, patches, depth_edges, points_3d, angles, lab, texture};
-    size_t in_total = 0;
-    for (size_t b : in_sizes) in_total += up8(b);
-    FS_HIP(ctx->st_in.ensure(in_total));
-    char *in_dev[7];
-    {
-        char *p = ctx->st_in.as<char>();
-        for (int i = 0; i < 7; ++i) {
-            in_dev[i] = p;
-            if (in_sizes[i]) FS_HIP(hipMemcpyAsync(p, in_host[i], in_sizes[i], hipMemcpyHostToDevice, ctx->stream));
-            p += up8(in_sizes[i]);
-        }
-    }
-    StatsIn in{};
-    in.surfaces = reinterpret_cast<const int64_t *>(in_dev[0]);
-    in.patches = reinterpret_cast<const int64_t *>(in_dev[1]);
-    in.depth_edges = reinterpret_cast<const int32_t *>(in_dev[2]);
-    in.points_3d = reinterpret_cast<const float *>(in_dev[3]);
-    in.angles = reinterpret_cast<const float *>(in_dev[4]);
-    in.lab = reinterpret_cast<const double *>(in_dev[5]);
-    in.texture = texture ? reinterpret_cast<const float *>(in_dev[6]) : nullptr;
-    void *const none[kStatsOutputs] = {};
-    char *od[kStatsOutputs];
-    size_t out_sizes[kStatsOutputs];
-    if (surface_stats_core(ctx, "fs_surface_stats", S, T, in, none, od, out_sizes)) return -1;
-    void *host_out[kStatsOutputs] = {surfaces_out, patch_point_offsets, patch_points, avg_pos, counts, centroids, centroid_indices,
-                                     hist_color, hist_angle, hist_texture, avg_angles, neighbors, border_centers, norm, depth_extend};
-    for (int i = 0; i < kStatsOutputs; ++i)
-        if (host_out[i]) FS_HIP(hipMemcpyAsync(host_out[i], od[i], out_sizes[i], hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    void *const host_out[kStatsOutputs] = {surfaces_out, patch_point_offsets, patch_points, avg_pos, counts, centroids, centroid_indices,
+                                           hist_color, hist_angle, hist_texture, avg_angles, neighbors, border_centers, norm, depth_extend};
+    if (ctx && !lab) return ctx->fail("fs_surface_stats: null input");
+    return surface_stats_host(ctx, "fs_surface_stats", num_surfaces, surfaces, patches, depth_edges, points_3d, angles, lab, nullptr, texture,
+                              texture_dim, nullptr, host_out);
+}
+
+int fs_surface_stats_rgb(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, const int64_t *patches, const int32_t *depth_edges,
+                         const float *points_3d, const float *angles, const uint8_t *rgb, const float *texture, int texture_dim,
+                         double *lab_out, int64_t *surfaces_out, int32_t *patch_point_offsets, float *patch_points, double *avg_pos,
+                         double *counts, float *centroids, int32_t *centroid_indices, double *hist_color, double *hist_angle,
+                         double *hist_texture, double *avg_angles, double *neighbors, double *border_centers, float *norm,
+                         float *depth_extend)
+{
+    void *const host_out[kStatsOutputs] = {surfaces_out, patch_point_offsets, patch_points, avg_pos, counts, centroids, centroid_indices,
+                                           hist_color, hist_angle, hist_texture, avg_angles, neighbors, border_centers, norm, depth_extend};
+    if (ctx && !rgb) return ctx->fail("fs_surface_stats_rgb: null input");
+    return surface_stats_host(ctx, "fs_surface_stats_rgb", num_surfaces, surfaces, patches, depth_edges, points_3d, angles, nullptr, rgb,
+                              texture, texture_dim, lab_out, host_out);
 }
 
 int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surfaces, const int64_t *d_patches,
@@ -1045,26 +1140,43 @@ int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surface
                          double *d_hist_color, double *d_hist_angle, double *d_hist_texture, double *d_avg_angles,
                          double *d_neighbors, double *d_border_centers, float *d_norm, float *d_depth_extend)
 {
+    const int32_t S = num_surfaces;
+    return fs_surface_stats_batch_dev(ctx, 1, &S, d_surfaces, d_patches, d_depth_edges, d_points_3d, d_angles, d_lab, nullptr, d_texture,
+                                      texture_dim, nullptr, d_surfaces_out, d_patch_point_offsets, d_patch_points, d_avg_pos, d_counts,
+                                      d_centroids, d_centroid_indices, d_hist_color, d_hist_angle, d_hist_texture, d_avg_angles, d_neighbors,
+                                      d_border_centers, d_norm, d_depth_extend);
+}
+
+int fs_surface_stats_batch_dev(fs_ctx *ctx, int n, const int32_t *num_surfaces, const int64_t *d_surfaces, const int64_t *d_patches,
+                               const int32_t *d_depth_edges, const float *d_points_3d, const float *d_angles, const double *d_lab,
+                               const uint8_t *d_rgb, const float *d_texture, int texture_dim, double *d_lab_out, int64_t *d_surfaces_out,
+                               int32_t *d_patch_point_offsets, float *d_patch_points, double *d_avg_pos, double *d_counts,
+                               float *d_centroids, int32_t *d_centroid_indices, double *d_hist_color, double *d_hist_angle,
+                               double *d_hist_texture, double *d_avg_angles, double *d_neighbors, double *d_border_centers, float *d_norm,
+                               float *d_depth_extend)
+{
     if (!ctx) return -1;
     if (set_device(ctx)) return -1;
-    const int S = num_surfaces, T = texture_dim;
-    if (stats_check_args(ctx, "fs_surface_stats_dev", S, T, d_texture != nullptr,
-                         d_surfaces && d_patches && d_depth_edges && d_points_3d && d_angles && d_lab))
+    const int T = texture_dim;
+    if (stats_check_args(ctx, "fs_surface_stats_batch_dev", n, num_surfaces, T, d_texture != nullptr,
+                         d_surfaces && d_patches && d_depth_edges && d_points_3d && d_angles && (d_lab || d_rgb)))
         return -1;
-    StatsIn in{};
+    StatsInputs in{};
     in.surfaces = d_surfaces;
     in.patches = d_patches;
-    in.depth_edges = d_depth_edges;
+    in.edges = d_depth_edges;
     in.points_3d = d_points_3d;
     in.angles = d_angles;
     in.lab = d_lab;
+    in.rgb = d_lab ? nullptr : d_rgb;
     in.texture = d_texture;
+    in.lab_out = d_lab_out;
     void *const user_out[kStatsOutputs] = {d_surfaces_out, d_patch_point_offsets, d_patch_points, d_avg_pos, d_counts, d_centroids,
                                            d_centroid_indices, d_hist_color, d_hist_angle, d_hist_texture, d_avg_angles, d_neighbors,
                                            d_border_centers, d_norm, d_depth_extend};
     char *od[kStatsOutputs];
     size_t out_sizes[kStatsOutputs];
-    return surface_stats_core(ctx, "fs_surface_stats_dev", S, T, in, user_out, od, out_sizes) ? -1 : 0;
+    return surface_stats_core(ctx, "fs_surface_stats_batch_dev", n, num_surfaces, T, in, user_out, od, out_sizes) ? -1 : 0;
 }
 
 int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int S, int pool_h, int pool_w, int stride_h, int stride_w,

@@ -82,38 +82,49 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
 // components of a label image (equal non-zero values, 4-connectivity): parent[p] = flat index of the first
 // pixel of p's component (-1 where the label is 0), count[root] = pixels of the component
 void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st);
-// per-surface statistics of one frame (k_stats.hip); every pointer is device memory
-struct StatsIn {
-    const int64_t *surfaces, *patches;   // [H][W]
-    const int32_t *depth_edges;          // [H][W]
+// per-surface statistics (k_stats.hip): one descriptor per frame of a batch; every pointer is device memory
+struct StatsFrame {
+    // inputs ([H][W] images of the frame)
+    const int64_t *surfaces, *patches;
+    const int32_t *edges;
     const float *points_3d, *angles;     // [H][W][3], [H][W][2]
-    const double *lab;                   // [H][W][3]
+    const double *lab;                   // [H][W][3]: the caller's, or lab_work when rgb is given
+    const uint8_t *rgb;                  // [H][W][3] or null
+    double *lab_work;                    // where the colour conversion writes (rgb != null)
     const float *texture;                // [H/4][W/4][T] or null
-};
-struct StatsWork {
-    int32_t *surf32, *pat32, *parent, *count;                     // [N] each
-    uint32_t *sort_key, *sort_key_out, *sort_val, *sort_val_out;  // [N] each
-    void *sort_temp;
-    size_t sort_temp_bytes;
-    void *scratch;                                                // stats_work_bytes(S, T)
-};
-struct StatsOut {
-    int64_t *surfaces;                   // [H][W] relabelled, disconnected parts removed
-    int32_t *patch_point_offsets;        // [S+1]
+    // label-indexed scratch (stats_carve_scratch)
+    unsigned long long *acc, *best, *nb_sum;
+    double *angle_sum, *tex_sum;
+    uint32_t *hist_color, *hist_angle, *nb_count, *cnt, *tex_cnt, *extent, *blockcnt;
+    int32_t *cpix;
+    // outputs
+    int64_t *surfaces_out;               // [H][W] relabelled, disconnected parts removed
+    int32_t *offsets;                    // [S+1]
     float *patch_points;                 // [N][2] (x, y), grouped by patch label, raster order inside a label
     double *avg_pos, *counts;            // [S][2], [S]
     float *centroids;                    // [S][3]
     int32_t *centroid_idx;               // [S][2] (y, x)
-    double *hist_color, *hist_angle, *hist_texture, *avg_angles;   // [256][256][S], [40][40][S], [S][T], [S][2]
+    double *hist_color_out, *hist_angle_out, *hist_texture_out, *avg_angles;   // [256][256][S], [40][40][S], [S][T], [S][2]
     double *neighbors;                   // [S][S] symmetric pair counts after the "< 4 -> 1" rule
     double *border_centers;              // [S][S][2]
     float *norm;                         // [H][W]
     float *depth_extend;                 // [S][4][2]
-    int *err;                            // 0 ok, 1 label out of range, 2 colour bin out of range, 3 angle bin out of range
+    int S;                               // num_surfaces of the frame
+    int pad_;
 };
-size_t stats_sort_temp_bytes(int N);
-size_t stats_work_bytes(int S, int T);
-hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const StatsOut &out, int H, int W, int S, int T, hipStream_t st);
+struct StatsBatchWork {
+    int32_t *surf32, *pat32, *parent, *count;   // [n][H*W] each
+    const double *lin;                          // [256] linearised sRGB channel values
+    uint32_t *ext_all;                          // the batch's min / max slots
+    size_t ext_words;
+    int *err;                                   // 0 ok, 1 label out of range, 2 colour bin out of range, 3 angle bin out of range
+};
+struct StatsScratchSizes { size_t zero, ones, ext, plain; };
+StatsScratchSizes stats_scratch_sizes(int S, int T, int nblk);
+void stats_carve_scratch(StatsFrame &f, int T, int nblk, char *zero, char *ones, char *ext, char *plain);
+int stats_blocks_per_frame(int H, int W);
+hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame *frames_host, int n, const StatsBatchWork &w, int H, int W,
+                                      int T, hipStream_t st);
 // pairwise reductions (k_pairs.hip); device pointers.  pooled: S * PA * PB floats of scratch, out [S][S]
 void launch_chi_squared(const double *hist, float *pooled, float *out, int A, int B, int S, int ph, int pw, int sh, int sw,
                         hipStream_t st);

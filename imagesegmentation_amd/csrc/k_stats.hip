@@ -10,9 +10,10 @@
 //   calculate_depth_extend                             :332-346
 // All of it is HBM-bound integer / byte work: one pass per dependency level, per-block
 // privatisation in LDS of everything indexed by label, one global atomic per (block, label).
+// Every kernel works on a batch: blockIdx.y (blockIdx.x for the one-block-per-frame kernels) is the frame,
+// frames[] holds its label count, its label-indexed scratch and its output pointers; the int32 working copies of
+// the label images are [n][H*W] arrays.
 #include <algorithm>
-
-#include <hipcub/hipcub.hpp>
 
 #include "fs_common.h"
 
@@ -49,26 +50,51 @@ __device__ __forceinline__ void wave_histogram_add(uint32_t *__restrict__ hist, 
     }
 }
 
-// relabel, int32 working copies, interior counts and position sums, patch-pixel counts, sort input
-__global__ __launch_bounds__(SB) void stats_prepare_kernel(const int64_t *__restrict__ surfaces, const int64_t *__restrict__ patches,
-                                                           int32_t *__restrict__ surf32, int32_t *__restrict__ pat32,
-                                                           uint32_t *__restrict__ sort_key, uint32_t *__restrict__ sort_val,
-                                                           unsigned long long *__restrict__ acc, int *__restrict__ err, int H, int W, int S)
+// CIE L*a*b* of an sRGB pixel (D65, 2-degree observer): the definition utils.rgb_to_Lab restates for
+// skimage.color.rgb2lab (utils.py:7-8 of the reference).  lin[v] = linearised channel value of byte v.
+__global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin, int N)
+{
+    const StatsFrame &f = frames[blockIdx.y];
+    const int p = blockIdx.x * SB + threadIdx.x;
+    if (p >= N || !f.rgb) return;
+    const double r = lin[f.rgb[3 * (size_t)p]], g = lin[f.rgb[3 * (size_t)p + 1]], b = lin[f.rgb[3 * (size_t)p + 2]];
+    const double xyz[3] = {((r * 0.412453 + g * 0.357580) + b * 0.180423) / 0.95047, ((r * 0.212671 + g * 0.715160) + b * 0.072169) / 1.0,
+                           ((r * 0.019334 + g * 0.119193) + b * 0.950227) / 1.08883};
+    double t[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = xyz[c] > 0.008856 ? cbrt(xyz[c]) : 7.787 * xyz[c] + 16.0 / 116.0;
+    double *o = f.lab_work + 3 * (size_t)p;
+    o[0] = 116.0 * t[1] - 16.0;
+    o[1] = 500.0 * (t[0] - t[1]);
+    o[2] = 200.0 * (t[1] - t[2]);
+}
+
+// relabel, int32 working copies, interior counts and position sums, patch-pixel counts per block (the input of
+// the counting sort that builds the point lists)
+__global__ __launch_bounds__(SB) void stats_prepare_kernel(const StatsFrame *__restrict__ frames, int32_t *__restrict__ surf32_all,
+                                                           int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W)
 {
     extern __shared__ uint32_t sh[];             // [4][S]: interior count, sum x, sum y, patch count
-    const int N = H * W;
+    const StatsFrame &f = frames[blockIdx.y];
+    const int N = H * W, S = f.S;
+    const int64_t *__restrict__ surfaces = f.surfaces, *__restrict__ patches = f.patches;
+    int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * N, *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * N;
+    unsigned long long *__restrict__ acc = f.acc;
     for (int i = threadIdx.x; i < 4 * S; i += SB) sh[i] = 0u;
     __syncthreads();
     for (int k = 0; k < SPB / SB; ++k) {
         const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
         if (p >= N) continue;
         const int64_t pl = patches[p], sl = surfaces[p];
-        if (pl < 0 || pl >= S || sl < 0 || sl >= S) { *err = 1; continue; }   // every lane that writes stores the same value
+        if (pl < 0 || pl >= S || sl < 0 || sl >= S) {          // every lane that writes stores the same value
+            *err = 1;
+            surf32[p] = 0;
+            pat32[p] = 0;
+            continue;
+        }
         const int s = pl != 0 ? (int)pl : (int)sl;
         surf32[p] = s;
         pat32[p] = (int)pl;
-        sort_key[p] = (uint32_t)pl;
-        sort_val[p] = (uint32_t)p;
         atomicAdd(&sh[3 * S + (int)pl], 1u);
         const int y = p / W, x = p - y * W;
         if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
@@ -80,13 +106,19 @@ __global__ __launch_bounds__(SB) void stats_prepare_kernel(const int64_t *__rest
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * S; i += SB)
         if (sh[i]) atomicAdd(acc + i, (unsigned long long)sh[i]);
+    for (int i = threadIdx.x; i < S; i += SB) f.blockcnt[(size_t)blockIdx.x * S + i] = sh[3 * S + i];
 }
 
-// one block: patch-point offsets (exclusive scan), counts and average positions
-__global__ __launch_bounds__(1024) void stats_offsets_kernel(const unsigned long long *__restrict__ acc, int32_t *__restrict__ offsets,
-                                                             double *__restrict__ avg_pos, double *__restrict__ counts, int S)
+// one block per frame: patch-point offsets (exclusive scan over the labels), counts and average positions, and
+// the counting sort's second step: blockcnt[b][l] becomes the position of block b's first pixel of label l
+__global__ __launch_bounds__(1024) void stats_offsets_kernel(const StatsFrame *__restrict__ frames, int nblk)
 {
     __shared__ int part[1024];
+    const StatsFrame &f = frames[blockIdx.x];
+    const int S = f.S;
+    const unsigned long long *__restrict__ acc = f.acc;
+    int32_t *__restrict__ offsets = f.offsets;
+    double *__restrict__ avg_pos = f.avg_pos, *__restrict__ counts = f.counts;
     const int t = threadIdx.x;
     const int v = t < S ? (int)acc[3 * S + t] : 0;
     part[t] = v;
@@ -104,16 +136,63 @@ __global__ __launch_bounds__(1024) void stats_offsets_kernel(const unsigned long
         counts[t] = c;
         avg_pos[2 * t] = c > 0 ? (double)acc[S + t] / c : 0.0;
         avg_pos[2 * t + 1] = c > 0 ? (double)acc[2 * S + t] / c : 0.0;
+        uint32_t run = (uint32_t)(part[t] - v);
+        for (int b = 0; b < nblk; ++b) {
+            const uint32_t c0 = f.blockcnt[(size_t)b * S + t];
+            f.blockcnt[(size_t)b * S + t] = run;
+            run += c0;
+        }
     }
 }
 
-__global__ __launch_bounds__(SB) void stats_points_kernel(const uint32_t *__restrict__ sorted_idx, float2 *__restrict__ points, int N, int W)
+// extract_individual_points_from_surfaces (:96-108) is a stable counting sort of the pixels by patch label.  A block
+// holds 1024 consecutive pixels as 16 segments of 64 (one wave, one pass); a pixel's position in its label's list is
+// blockcnt[block][label] + the label's pixels in the block's earlier segments + those in lower lanes of its own wave.
+__global__ __launch_bounds__(SB) void stats_points_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ pat32_all,
+                                                          int N, int W)
 {
-    const int k = blockIdx.x * SB + threadIdx.x;
-    if (k >= N) return;
-    const uint32_t p = sorted_idx[k];
-    const uint32_t y = p / W;
-    points[k] = make_float2((float)(p - y * W), (float)y);
+    extern __shared__ uint32_t seg[];            // [16][S]
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const int32_t *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * N;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * S; i += SB) seg[i] = 0u;
+    __syncthreads();
+    int lab[SPB / SB], rank[SPB / SB];
+#pragma unroll
+    for (int k = 0; k < SPB / SB; ++k) {
+        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+        const bool in = p < N;
+        lab[k] = in ? pat32[p] : -1;
+        rank[k] = 0;
+        unsigned long long todo = __ballot(in);
+        while (todo) {                           // a wave of consecutive pixels holds few labels
+            const int leader = __ffsll((long long)todo) - 1;
+            const int key = __shfl(lab[k], leader);
+            const unsigned long long same = __ballot(lab[k] == key) & todo;
+            if (lab[k] == key) rank[k] = __popcll(same & ((1ull << lane) - 1ull));
+            if (lane == leader) seg[(k * 4 + wv) * S + key] = (uint32_t)__popcll(same);
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < S; l += SB) {
+        uint32_t run = f.blockcnt[(size_t)blockIdx.x * S + l];
+        for (int sg = 0; sg < 16; ++sg) {
+            const uint32_t c0 = seg[sg * S + l];
+            seg[sg * S + l] = run;
+            run += c0;
+        }
+    }
+    __syncthreads();
+    float2 *__restrict__ points = reinterpret_cast<float2 *>(f.patch_points);
+#pragma unroll
+    for (int k = 0; k < SPB / SB; ++k) {
+        if (lab[k] < 0) continue;
+        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+        const int y = p / W;
+        points[seg[(k * 4 + wv) * S + lab[k]] + rank[k]] = make_float2((float)(p - y * W), (float)y);
+    }
 }
 
 __device__ __forceinline__ unsigned long long dist_bits(int p, int W, const double *avg_pos, int l)
@@ -125,10 +204,15 @@ __device__ __forceinline__ unsigned long long dist_bits(int p, int W, const doub
 
 // pass 1: smallest squared distance per label; pass 2: smallest pixel index among the pixels that attain it
 template <int PASS>
-__global__ __launch_bounds__(SB) void stats_centroid_kernel(const int32_t *__restrict__ pat32, const double *__restrict__ avg_pos,
-                                                            unsigned long long *__restrict__ best, int N, int W, int S)
+__global__ __launch_bounds__(SB) void stats_centroid_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ pat32_all,
+                                                            int N, int W)
 {
     extern __shared__ unsigned long long shb[];  // [S]
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const int32_t *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * N;
+    const double *__restrict__ avg_pos = f.avg_pos;
+    unsigned long long *__restrict__ best = f.best;
     for (int i = threadIdx.x; i < S; i += SB) shb[i] = ~0ull;
     __syncthreads();
     for (int k = 0; k < SPB / SB; ++k) {
@@ -148,10 +232,14 @@ __global__ __launch_bounds__(SB) void stats_centroid_kernel(const int32_t *__res
         if (shb[i] != ~0ull) atomicMin(dst + i, shb[i]);
 }
 
-__global__ __launch_bounds__(SB) void stats_centroid_finish_kernel(const unsigned long long *__restrict__ best, const float *__restrict__ points_3d,
-                                                                   float *__restrict__ centroids, int32_t *__restrict__ centroid_idx,
-                                                                   int32_t *__restrict__ cpix, int W, int S)
+__global__ __launch_bounds__(SB) void stats_centroid_finish_kernel(const StatsFrame *__restrict__ frames, int W)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const unsigned long long *__restrict__ best = f.best;
+    const float *__restrict__ points_3d = f.points_3d;
+    float *__restrict__ centroids = f.centroids;
+    int32_t *__restrict__ centroid_idx = f.centroid_idx, *__restrict__ cpix = f.cpix;
     const int l = blockIdx.x * SB + threadIdx.x;
     if (l >= S) return;
     const unsigned long long b = best[S + l];
@@ -169,9 +257,13 @@ __global__ __launch_bounds__(SB) void stats_centroid_finish_kernel(const unsigne
 }
 
 // keep a pixel iff it lies in the component of its label's centroid pixel (or is the start pixel of label 0's fill)
-__global__ __launch_bounds__(SB) void stats_keep_kernel(int32_t *__restrict__ surf32, const int32_t *__restrict__ parent,
-                                                        const int32_t *__restrict__ cpix, int64_t *__restrict__ surfaces_out, int N)
+__global__ __launch_bounds__(SB) void stats_keep_kernel(const StatsFrame *__restrict__ frames, int32_t *__restrict__ surf32_all,
+                                                        const int32_t *__restrict__ parent_all, int N)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * N;
+    const int32_t *__restrict__ parent = parent_all + (size_t)blockIdx.y * N, *__restrict__ cpix = f.cpix;
+    int64_t *__restrict__ surfaces_out = f.surfaces_out;
     const int p = blockIdx.x * SB + threadIdx.x;
     if (p >= N) return;
     const int s = surf32[p];
@@ -186,15 +278,20 @@ __global__ __launch_bounds__(SB) void stats_keep_kernel(int32_t *__restrict__ su
 }
 
 // histograms, angle sums, neighbour counts and border sums, norm and per-label extents
-__global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__restrict__ surf32, const int32_t *__restrict__ pat32,
-                                                              const int32_t *__restrict__ edges, const double *__restrict__ lab,
-                                                              const float *__restrict__ angles, const float *__restrict__ points_3d,
-                                                              uint32_t *__restrict__ hist_color, uint32_t *__restrict__ hist_angle,
-                                                              double *__restrict__ angle_sum, uint32_t *__restrict__ cnt,
-                                                              uint32_t *__restrict__ nb_count, unsigned long long *__restrict__ nb_sum,
-                                                              float *__restrict__ norm, uint32_t *__restrict__ extent, int *__restrict__ err,
-                                                              int H, int W, int S)
+__global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ surf32_all,
+                                                              const int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * H * W, *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * H * W;
+    const int32_t *__restrict__ edges = f.edges;
+    const double *__restrict__ lab = f.lab;
+    const float *__restrict__ angles = f.angles, *__restrict__ points_3d = f.points_3d;
+    uint32_t *__restrict__ hist_color = f.hist_color, *__restrict__ hist_angle = f.hist_angle, *__restrict__ cnt = f.cnt;
+    uint32_t *__restrict__ nb_count = f.nb_count, *__restrict__ extent = f.extent;
+    double *__restrict__ angle_sum = f.angle_sum;
+    unsigned long long *__restrict__ nb_sum = f.nb_sum;
+    float *__restrict__ norm = f.norm;
     // per-block copies of everything indexed by label: global atomics on one address per label would
     // serialise (a patch has ~1e5 pixels), LDS atomics do not
     extern __shared__ double shd[];              // [S][2] angle sums | then uint32: [S][8] min/max of (norm, x, y, z) | [S] surface count | [S] patch count
@@ -280,10 +377,15 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const int32_t *__r
 }
 
 // texture vectors of every 4th pixel of a patch, :278-283: one block per texture row, a thread per component
-__global__ __launch_bounds__(SB) void stats_texture_kernel(const int32_t *__restrict__ surf32, const int32_t *__restrict__ pat32,
-                                                           const float *__restrict__ texture, double *__restrict__ tex_sum,
-                                                           uint32_t *__restrict__ tex_cnt, int W, int TW, int T)
+__global__ __launch_bounds__(SB) void stats_texture_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ surf32_all,
+                                                           const int32_t *__restrict__ pat32_all, int N, int W, int TW, int T)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    const float *__restrict__ texture = f.texture;
+    if (!texture) return;
+    const int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * N, *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * N;
+    double *__restrict__ tex_sum = f.tex_sum;
+    uint32_t *__restrict__ tex_cnt = f.tex_cnt;
     const int ty = blockIdx.x;
     // consecutive texture pixels of one label are summed in registers before touching memory
     for (int c = threadIdx.x; c < T; c += SB) {
@@ -312,13 +414,16 @@ __global__ __launch_bounds__(SB) void stats_texture_kernel(const int32_t *__rest
 }
 
 // normalisations of :284-295 and conversion to the float64 outputs
-__global__ __launch_bounds__(SB) void stats_finalize_kernel(const uint32_t *__restrict__ hist_color, const uint32_t *__restrict__ hist_angle,
-                                                            const double *__restrict__ angle_sum, const uint32_t *__restrict__ cnt,
-                                                            const double *__restrict__ tex_sum, const uint32_t *__restrict__ tex_cnt,
-                                                            const uint32_t *__restrict__ extent, double *__restrict__ out_color,
-                                                            double *__restrict__ out_angle, double *__restrict__ out_texture,
-                                                            double *__restrict__ out_avg_angles, float *__restrict__ out_extent, int S, int T)
+__global__ __launch_bounds__(SB) void stats_finalize_kernel(const StatsFrame *__restrict__ frames, int T)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const uint32_t *__restrict__ hist_color = f.hist_color, *__restrict__ hist_angle = f.hist_angle, *__restrict__ cnt = f.cnt;
+    const uint32_t *__restrict__ tex_cnt = f.tex_cnt, *__restrict__ extent = f.extent;
+    const double *__restrict__ angle_sum = f.angle_sum, *__restrict__ tex_sum = f.tex_sum;
+    double *__restrict__ out_color = f.hist_color_out, *__restrict__ out_angle = f.hist_angle_out, *__restrict__ out_texture = f.hist_texture_out;
+    double *__restrict__ out_avg_angles = f.avg_angles;
+    float *__restrict__ out_extent = f.depth_extend;
     const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
     const size_t n_color = (size_t)256 * 256 * S, n_angle = (size_t)40 * 40 * S, n_tex = (size_t)S * T;
     if (i < n_color) {
@@ -354,10 +459,13 @@ __global__ __launch_bounds__(SB) void stats_finalize_kernel(const uint32_t *__re
 // pair was counted once, in the direction it was met; the reference adds it to both entries, zeroes row 0, column 0
 // and the diagonal, replaces every count below 4 by 1 (the diagonal and row/column 0 included: they are 0 by then)
 // and divides the coordinate sums by twice the count.
-__global__ __launch_bounds__(SB) void stats_neighbors_kernel(const uint32_t *__restrict__ nb_count,
-                                                             const unsigned long long *__restrict__ nb_sum,
-                                                             double *__restrict__ neighbors, double *__restrict__ border_centers, int S)
+__global__ __launch_bounds__(SB) void stats_neighbors_kernel(const StatsFrame *__restrict__ frames)
 {
+    const StatsFrame &f = frames[blockIdx.y];
+    const int S = f.S;
+    const uint32_t *__restrict__ nb_count = f.nb_count;
+    const unsigned long long *__restrict__ nb_sum = f.nb_sum;
+    double *__restrict__ neighbors = f.neighbors, *__restrict__ border_centers = f.border_centers;
     const size_t a = (size_t)blockIdx.x * SB + threadIdx.x;
     if (a >= (size_t)S * S) return;
     const int i = (int)(a / S), j = (int)(a - (size_t)i * S);
@@ -372,6 +480,7 @@ __global__ __launch_bounds__(SB) void stats_neighbors_kernel(const uint32_t *__r
     border_centers[2 * a + 1] = sy / (2 * n);
 }
 
+// extent[i] = ~0 (minimum slots) / 0 (maximum slots) for the whole batch
 __global__ __launch_bounds__(SB) void stats_fill_kernel(uint32_t *__restrict__ a, size_t n, uint32_t even, uint32_t odd)
 {
     const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
@@ -380,77 +489,76 @@ __global__ __launch_bounds__(SB) void stats_fill_kernel(uint32_t *__restrict__ a
 
 }  // namespace
 
-size_t stats_sort_temp_bytes(int N)
+// Label-indexed scratch of one frame, in four regions of the batch's scratch buffer so that the whole batch is
+// initialised by three calls: `zero` (cleared), `ones` (0xff: the centroid search), `ext` (min / max pattern) and
+// `plain` (written before it is read).
+StatsScratchSizes stats_scratch_sizes(int S, int T, int nblk)
 {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                             (uint32_t *)nullptr, N, 0, 10);
-    return bytes;
+    StatsScratchSizes z;
+    // acc[4S] u64 | nb_sum[2SS] u64 | angle_sum[2S] f64 | tex_sum[S*T] f64 | hist_color u32 | hist_angle u32 | nb_count[SS] u32 |
+    // cnt[2S] u32 | tex_cnt[S] u32 (+ pad)
+    z.zero = 8 * ((size_t)4 * S + 2 * (size_t)S * S + 2 * S + (size_t)S * T) +
+             4 * (((size_t)256 * 256 * S + 1600 * (size_t)S + (size_t)S * S + 2 * S + S + 1) / 2 * 2);
+    z.ones = 8 * (size_t)2 * S;                                   // best[2S] u64
+    z.ext = 4 * (size_t)8 * S;                                    // extent[8S] u32
+    z.plain = 4 * (((size_t)S + (size_t)nblk * S + 1) / 2 * 2);   // cpix[S] i32 | blockcnt[nblk][S] u32
+    return z;
 }
 
-size_t stats_work_bytes(int S, int T)
+void stats_carve_scratch(StatsFrame &f, int T, int nblk, char *zero, char *ones, char *ext, char *plain)
 {
-    // acc[4S] u64 | best[2S] u64 | nb_sum[2SS] u64 | angle_sum[2S] f64 | tex_sum[S*T] f64 | hist_color u32 | hist_angle u32 |
-    // nb_count[SS] u32 | cnt[2S] u32 | tex_cnt[S] u32 | extent[8S] u32 | cpix[S] i32 | err i32
-    return 8 * ((size_t)4 * S + 2 * S + 2 * (size_t)S * S + 2 * S + (size_t)S * T) +
-           4 * ((size_t)256 * 256 * S + 1600 * (size_t)S + (size_t)S * S + 2 * S + S + 8 * S + S + 2);
+    const size_t S = f.S;
+    auto take = [](char *&base, size_t bytes) { char *p = base; base += bytes; return p; };
+    f.acc = reinterpret_cast<unsigned long long *>(take(zero, 8 * 4 * S));
+    f.nb_sum = reinterpret_cast<unsigned long long *>(take(zero, 8 * 2 * S * S));
+    f.angle_sum = reinterpret_cast<double *>(take(zero, 8 * 2 * S));
+    f.tex_sum = reinterpret_cast<double *>(take(zero, 8 * S * T));
+    f.hist_color = reinterpret_cast<uint32_t *>(take(zero, 4 * (size_t)256 * 256 * S));
+    f.hist_angle = reinterpret_cast<uint32_t *>(take(zero, 4 * (size_t)1600 * S));
+    f.nb_count = reinterpret_cast<uint32_t *>(take(zero, 4 * S * S));
+    f.cnt = reinterpret_cast<uint32_t *>(take(zero, 4 * 2 * S));
+    f.tex_cnt = reinterpret_cast<uint32_t *>(take(zero, 4 * S));
+    f.best = reinterpret_cast<unsigned long long *>(ones);
+    f.extent = reinterpret_cast<uint32_t *>(ext);
+    f.cpix = reinterpret_cast<int32_t *>(take(plain, 4 * S));
+    f.blockcnt = reinterpret_cast<uint32_t *>(take(plain, 4 * (size_t)nblk * S));
 }
 
-hipError_t launch_surface_stats(const StatsIn &in, const StatsWork &w, const StatsOut &out, int H, int W, int S, int T, hipStream_t st)
+int stats_blocks_per_frame(int H, int W) { return (H * W + SPB - 1) / SPB; }
+
+// frames: device array of n descriptors (host copy in frames_host for the launch geometry); surf32 / pat32 / parent /
+// count: [n][H*W] int32 work arrays; lin: 256 linearised sRGB channel values (used when a frame gives rgb instead of lab);
+// ext_all / ext_words: the batch's extent region; err: one int, cleared by the caller.
+hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame *frames_host, int n, const StatsBatchWork &w, int H, int W,
+                                      int T, hipStream_t st)
 {
     const int N = H * W;
-    const int nblk = (N + SPB - 1) / SPB;
-    // carve the label-indexed scratch
-    char *base = static_cast<char *>(w.scratch);
-    auto take = [&](size_t bytes) { char *p = base; base += (bytes + 7) / 8 * 8; return p; };
-    auto *acc = reinterpret_cast<unsigned long long *>(take(8 * (size_t)4 * S));
-    auto *best = reinterpret_cast<unsigned long long *>(take(8 * (size_t)2 * S));
-    auto *nb_sum = reinterpret_cast<unsigned long long *>(take(8 * 2 * (size_t)S * S));
-    auto *angle_sum = reinterpret_cast<double *>(take(8 * (size_t)2 * S));
-    auto *tex_sum = reinterpret_cast<double *>(take(8 * (size_t)S * T));
-    auto *hist_color = reinterpret_cast<uint32_t *>(take(4 * (size_t)256 * 256 * S));
-    auto *hist_angle = reinterpret_cast<uint32_t *>(take(4 * (size_t)1600 * S));
-    auto *nb_count = reinterpret_cast<uint32_t *>(take(4 * (size_t)S * S));
-    auto *cnt = reinterpret_cast<uint32_t *>(take(4 * (size_t)2 * S));
-    auto *tex_cnt = reinterpret_cast<uint32_t *>(take(4 * (size_t)S));
-    auto *extent = reinterpret_cast<uint32_t *>(take(4 * (size_t)8 * S));
-    auto *cpix = reinterpret_cast<int32_t *>(take(4 * (size_t)S));
-    auto *err = reinterpret_cast<int *>(take(8));
-    const size_t zero_bytes = (size_t)(reinterpret_cast<char *>(extent) - static_cast<char *>(w.scratch));
-    hipError_t e = hipMemsetAsync(w.scratch, 0, zero_bytes, st);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(best, 0xff, 8 * (size_t)2 * S, st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(err, 0, 8, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(stats_fill_kernel, dim3((8 * S + SB - 1) / SB), dim3(SB), 0, st, extent, (size_t)8 * S, ~0u, 0u);
-
-    hipLaunchKernelGGL(stats_prepare_kernel, dim3(nblk), dim3(SB), 4 * S * sizeof(uint32_t), st, in.surfaces, in.patches, w.surf32,
-                       w.pat32, w.sort_key, w.sort_val, acc, err, H, W, S);
-    hipLaunchKernelGGL(stats_offsets_kernel, dim3(1), dim3(1024), 0, st, acc, out.patch_point_offsets, out.avg_pos, out.counts, S);
-    int bits = 1;
-    while ((1 << bits) < S) ++bits;
-    size_t temp = w.sort_temp_bytes;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(w.sort_temp, temp, w.sort_key, w.sort_key_out, w.sort_val, w.sort_val_out, N, 0, bits,
-                                                st)) != hipSuccess)
-        return e;
-    hipLaunchKernelGGL(stats_points_kernel, dim3((N + SB - 1) / SB), dim3(SB), 0, st, w.sort_val_out, reinterpret_cast<float2 *>(out.patch_points), N, W);
-    hipLaunchKernelGGL(stats_centroid_kernel<1>, dim3(nblk), dim3(SB), S * sizeof(unsigned long long), st, w.pat32, out.avg_pos, best, N, W, S);
-    hipLaunchKernelGGL(stats_centroid_kernel<2>, dim3(nblk), dim3(SB), S * sizeof(unsigned long long), st, w.pat32, out.avg_pos, best, N, W, S);
-    hipLaunchKernelGGL(stats_centroid_finish_kernel, dim3((S + SB - 1) / SB), dim3(SB), 0, st, best, in.points_3d, out.centroids,
-                       out.centroid_idx, cpix, W, S);
-    launch_label_components(w.surf32, w.parent, w.count, 1, H, W, st);
-    hipLaunchKernelGGL(stats_keep_kernel, dim3((N + SB - 1) / SB), dim3(SB), 0, st, w.surf32, w.parent, cpix, out.surfaces, N);
-    hipLaunchKernelGGL(stats_accumulate_kernel, dim3(nblk), dim3(SB), 10 * S * sizeof(uint32_t) + 2 * S * sizeof(double), st, w.surf32, w.pat32, in.depth_edges,
-                       in.lab, in.angles, in.points_3d, hist_color, hist_angle, angle_sum, cnt, nb_count, nb_sum, out.norm, extent, err,
-                       H, W, S);
-    if (in.texture)
-        hipLaunchKernelGGL(stats_texture_kernel, dim3(H / 4), dim3(SB), 0, st, w.surf32, w.pat32, in.texture, tex_sum, tex_cnt, W, W / 4, T);
-    const size_t n_fin = std::max<size_t>((size_t)256 * 256 * S, (size_t)S * T);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((n_fin + SB - 1) / SB)), dim3(SB), 0, st, hist_color, hist_angle, angle_sum,
-                       cnt, tex_sum, tex_cnt, extent, out.hist_color, out.hist_angle, out.hist_texture, out.avg_angles,
-                       out.depth_extend, S, T);
-    hipLaunchKernelGGL(stats_neighbors_kernel, dim3((unsigned)(((size_t)S * S + SB - 1) / SB)), dim3(SB), 0, st, nb_count, nb_sum,
-                       out.neighbors, out.border_centers, S);
-    if ((e = hipMemcpyAsync(out.err, err, 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+    const int nblk = stats_blocks_per_frame(H, W);
+    int Smax = 1;
+    bool any_rgb = false, any_texture = false;
+    for (int i = 0; i < n; ++i) {
+        Smax = std::max(Smax, frames_host[i].S);
+        any_rgb |= frames_host[i].rgb != nullptr;
+        any_texture |= frames_host[i].texture != nullptr;
+    }
+    const dim3 by_pixel((N + SB - 1) / SB, n), by_block(nblk, n);
+    hipLaunchKernelGGL(stats_fill_kernel, dim3((unsigned)((w.ext_words + SB - 1) / SB)), dim3(SB), 0, st, w.ext_all, w.ext_words, ~0u, 0u);
+    if (any_rgb) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N);
+    hipLaunchKernelGGL(stats_prepare_kernel, by_block, dim3(SB), 4 * Smax * sizeof(uint32_t), st, frames, w.surf32, w.pat32, w.err, H, W);
+    hipLaunchKernelGGL(stats_offsets_kernel, dim3(n), dim3(1024), 0, st, frames, nblk);
+    hipLaunchKernelGGL(stats_points_kernel, by_block, dim3(SB), 16 * Smax * sizeof(uint32_t), st, frames, w.pat32, N, W);
+    hipLaunchKernelGGL(stats_centroid_kernel<1>, by_block, dim3(SB), Smax * sizeof(unsigned long long), st, frames, w.pat32, N, W);
+    hipLaunchKernelGGL(stats_centroid_kernel<2>, by_block, dim3(SB), Smax * sizeof(unsigned long long), st, frames, w.pat32, N, W);
+    hipLaunchKernelGGL(stats_centroid_finish_kernel, dim3((Smax + SB - 1) / SB, n), dim3(SB), 0, st, frames, W);
+    launch_label_components(w.surf32, w.parent, w.count, n, H, W, st);
+    hipLaunchKernelGGL(stats_keep_kernel, by_pixel, dim3(SB), 0, st, frames, w.surf32, w.parent, N);
+    hipLaunchKernelGGL(stats_accumulate_kernel, by_block, dim3(SB), 10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double), st, frames,
+                       w.surf32, w.pat32, w.err, H, W);
+    if (any_texture)
+        hipLaunchKernelGGL(stats_texture_kernel, dim3(H / 4, n), dim3(SB), 0, st, frames, w.surf32, w.pat32, N, W, W / 4, T);
+    const size_t n_fin = std::max<size_t>((size_t)256 * 256 * Smax, (size_t)Smax * T);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((n_fin + SB - 1) / SB), n), dim3(SB), 0, st, frames, T);
+    hipLaunchKernelGGL(stats_neighbors_kernel, dim3((unsigned)(((size_t)Smax * Smax + SB - 1) / SB), n), dim3(SB), 0, st, frames);
     return hipGetLastError();
 }
 

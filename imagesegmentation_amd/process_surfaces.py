@@ -34,13 +34,17 @@ def calc_depth_extend_distance(i, j, depth_extends):
 
 
 def create_depth_extend_distance_matrix(data):
-    """Symmetric matrix of calc_depth_extend_distance (process_surfaces.py:552-560)."""
-    S = data["num_surfaces"]
-    out = np.zeros((S, S))
-    for i in range(S):
-        for j in range(i + 1, S):
-            out[i, j] = out[j, i] = calc_depth_extend_distance(i, j, data["depth_extend"])
-    return out
+    """Symmetric matrix of calc_depth_extend_distance (process_surfaces.py:552-560): entry (i, j), i < j, is the distance
+    of the pair in that order, mirrored below the diagonal; all pairs at once instead of a Python double loop."""
+    de = np.asarray(data["depth_extend"])
+    d1, d2 = de[:, None], de[None, :]                       # [S,1,4,2], [1,S,4,2]
+    with np.errstate(invalid="ignore"):                      # labels without pixels carry (+inf, -inf) extents
+        overlap = ((d2[..., 0] <= d1[..., 0]) & (d1[..., 0] <= d2[..., 1])) | ((d2[..., 0] <= d1[..., 1]) & (d1[..., 1] <= d2[..., 1])) | \
+                  ((d1[..., 0] <= d2[..., 0]) & (d2[..., 1] <= d1[..., 1]))
+        gap = np.where(d1[..., 0] > d2[..., 1], d1[..., 0] - d2[..., 1], d2[..., 0] - d1[..., 1])
+    gap = np.where(overlap, 0, gap).astype(de.dtype)
+    upper = np.triu(np.max(gap, axis=-1).astype(np.float64), 1)
+    return upper + upper.T
 
 
 def calc_depth_extend_to_depth_extend_distance_ratio(data):
@@ -84,11 +88,12 @@ def extract_information_from_surface_data_and_preprocess_surfaces(data, texture_
     h, w = np.shape(data["patches"])
     S = int(data["num_surfaces"])
     data["texture"] = None if texture_model is None else texture_model(data["rgb"])
-    if "lab" not in data:
-        data["lab"] = utils.rgb_to_Lab(data["rgb"])
     ctx = _fs._context(h, w, _fs.standard_kernel_size)
-    st = ctx.surface_stats(data["surfaces"], data["patches"], data["depth_edges"], data["points_3d"], data["angles"], data["lab"],
-                           data["texture"], S)
+    # without a Lab image in the dict the colour conversion (utils.rgb_to_Lab in the reference) runs on the GPU
+    st = ctx.surface_stats(data["surfaces"], data["patches"], data["depth_edges"], data["points_3d"], data["angles"], data.get("lab"),
+                           data["texture"], S, rgb=data["rgb"])
+    if "lab" not in data:
+        data["lab"] = st["lab"]
     off = st["patch_point_offsets"]
     data["patch_points"] = [st["patch_points"][off[i]:off[i + 1]] for i in range(S)]
     data["surfaces"] = st["surfaces"]

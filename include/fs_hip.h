@@ -177,6 +177,15 @@ int fs_surface_stats(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, con
                      double *hist_color, double *hist_angle, double *hist_texture, double *avg_angles, double *neighbors,
                      double *border_centers, float *norm, float *depth_extend);
 
+/* The same with the frame's colours as rgb (uint8 [H][W][3], data["rgb"]) instead of lab: utils.rgb_to_Lab (utils.py:7-8,
+ * process_surfaces.py:678-679) runs on the device, and lab_out (float64 [H][W][3], may be NULL) receives data["lab"]. */
+int fs_surface_stats_rgb(fs_ctx *ctx, int num_surfaces, const int64_t *surfaces, const int64_t *patches,
+                         const int32_t *depth_edges, const float *points_3d, const float *angles, const uint8_t *rgb,
+                         const float *texture, int texture_dim, double *lab_out, int64_t *surfaces_out,
+                         int32_t *patch_point_offsets, float *patch_points, double *avg_pos, double *counts, float *centroids,
+                         int32_t *centroid_indices, double *hist_color, double *hist_angle, double *hist_texture,
+                         double *avg_angles, double *neighbors, double *border_centers, float *norm, float *depth_extend);
+
 /* The same stage with every array resident in device memory, for callers that keep the outputs of
  * fs_find_surfaces_batch_dev where they are: the arguments and layouts are those of fs_surface_stats, frame by
  * frame (process_surfaces.py:672-687 is a per-frame function), but every pointer is a device pointer.  Output
@@ -189,6 +198,25 @@ int fs_surface_stats_dev(fs_ctx *ctx, int num_surfaces, const int64_t *d_surface
                          int32_t *d_centroid_indices, double *d_hist_color, double *d_hist_angle, double *d_hist_texture,
                          double *d_avg_angles, double *d_neighbors, double *d_border_centers, float *d_norm,
                          float *d_depth_extend);
+
+/* The statistics stage for a batch of n frames resident in device memory, e.g. the outputs of
+ * fs_find_surfaces_batch_dev where they lie: the loop a caller of process_surfaces.py:672-687 would run over its frames,
+ * in one pass of batched kernels.  Input arrays hold the frames back to back ([n][H][W]...); num_surfaces[n] is a
+ * host array.  The colours come either as d_lab (float64 [n][H][W][3], data["lab"]) or as d_rgb (uint8 [n][H][W][3]):
+ * then utils.rgb_to_Lab (utils.py:7-8: sRGB -> CIE L*a*b*, D65) runs on the device and d_lab_out (may be NULL) receives
+ * the converted image.  Every output array holds the frames' parts back to back, frame i's part laid out as in
+ * fs_surface_stats with its own S = num_surfaces[i] (so the part of frame i starts at the sum of the sizes of frames
+ * 0 .. i-1: e.g. hist_color at 65536 * sum(S[0..i)) doubles, patch_point_offsets at sum(S[0..i)) + i ints).  Output
+ * pointers may be NULL.  Work is enqueued on the context's stream; the call synchronises once at the end to read the
+ * range-check flag. */
+int fs_surface_stats_batch_dev(fs_ctx *ctx, int n, const int32_t *num_surfaces, const int64_t *d_surfaces,
+                               const int64_t *d_patches, const int32_t *d_depth_edges, const float *d_points_3d,
+                               const float *d_angles, const double *d_lab, const uint8_t *d_rgb, const float *d_texture,
+                               int texture_dim, double *d_lab_out, int64_t *d_surfaces_out, int32_t *d_patch_point_offsets,
+                               float *d_patch_points, double *d_avg_pos, double *d_counts, float *d_centroids,
+                               int32_t *d_centroid_indices, double *d_hist_color, double *d_hist_angle,
+                               double *d_hist_texture, double *d_avg_angles, double *d_neighbors, double *d_border_centers,
+                               float *d_norm, float *d_depth_extend);
 
 /* chi_squared_distances_model_2D(pool_size, strides) (image_processing_models_GPU.py:189-200) applied to
  * one histogram stack: hist float64 [A][B][S] (e.g. hist_color [256][256][S] with pool (10,10), strides

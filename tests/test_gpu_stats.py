@@ -143,3 +143,77 @@ def test_surface_stats_device_pointers(oracle):
                 ctx.surface_stats_dev(0, *d_in[:6])
         finally:
             mem.free()
+
+
+def test_surface_stats_batch_dev_with_device_colour_conversion(oracle):
+    """fs_surface_stats_batch_dev on four frames of different label counts, consuming device-resident arrays (as
+    fs_find_surfaces_batch_dev leaves them) and uint8 colours: every frame's part of every output against the oracle
+    run frame by frame on utils.rgb_to_Lab's colours.  The device's Lab image agrees with the numpy one to 1e-10;
+    a colour bin could differ only for a pixel whose a or b + 127 lies within that distance of a half-integer."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.utils import rgb_to_Lab
+    idx = [5, 57, 80, 110]
+    frames = [osd_frame(i) for i in idx]
+    d = np.stack([f[0] for f in frames]).astype(np.uint16)
+    c = np.stack([f[1] for f in frames]).astype(np.uint8)
+    n, H, W = d.shape
+    T = 8
+    rng = np.random.default_rng(1)
+    tex = rng.random((n, H // 4, W // 4, T), dtype=np.float32)
+    dev = DeviceArrays()
+    try:
+        with Context(H, W, max_batch=n) as ctx:
+            fsr = ctx.find_surfaces_batch(d, c)
+            ns = fsr["num_surfaces"]
+            assert len(set(ns.tolist())) > 1
+            el = [ctx.stats_output_elements(H, W, int(s), T) for s in ns]
+            dtypes = {"surfaces": np.int64, "patch_point_offsets": np.int32, "patch_points": np.float32, "avg_pos": np.float64,
+                      "counts": np.float64, "centroids": np.float32, "centroid_indices": np.int32, "hist_color": np.float64,
+                      "hist_angle": np.float64, "hist_texture": np.float64, "avg_angles": np.float64, "neighbor_counts": np.float64,
+                      "border_centers": np.float64, "norm": np.float32, "depth_extend": np.float32}
+            total = {k: sum(e[k] for e in el) for k in dtypes}
+            ptr = {k: dev.alloc(total[k] * np.dtype(dt).itemsize) for k, dt in dtypes.items()}
+            d_lab = dev.alloc(n * H * W * 24)
+            ctx.surface_stats_batch_dev(ns, dev.upload(fsr["surfaces"]), dev.upload(fsr["patches"]), dev.upload(fsr["depth_edges"]),
+                                        dev.upload(fsr["points_3d"]), dev.upload(fsr["angles"]), d_rgb=dev.upload(c),
+                                        d_texture=dev.upload(tex), texture_dim=T, d_lab_out=d_lab, **ptr)
+            got = {k: dev.download(ptr[k], np.empty(total[k], dt)) for k, dt in dtypes.items()}
+            lab = dev.download(d_lab, np.empty((n, H, W, 3), np.float64))
+    finally:
+        dev.free()
+    exact = ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+             "hist_color", "hist_angle", "neighbor_counts", "border_centers", "norm", "depth_extend")
+    start = {k: 0 for k in dtypes}
+    for i in range(n):
+        lab_ref = rgb_to_Lab(c[i])
+        assert np.abs(lab[i] - lab_ref).max() <= 1e-10
+        want = oracle.surface_stats(fsr["surfaces"][i], fsr["patches"][i], fsr["depth_edges"][i], fsr["points_3d"][i], fsr["angles"][i],
+                                    lab_ref, tex[i], int(ns[i]))
+        for k in dtypes:
+            part = got[k][start[k]:start[k] + el[i][k]]
+            start[k] += el[i][k]
+            ref = np.asarray(want[k]).reshape(-1)
+            if k in exact:
+                assert np.array_equal(part, ref), (i, k)
+            else:
+                assert np.allclose(part, ref, rtol=1e-12, atol=1e-13), (i, k)
+
+
+def test_process_surfaces_mirror_converts_colours_on_the_device(oracle):
+    """extract_information_from_surface_data_and_preprocess_surfaces without a "lab" entry: the colour conversion runs on
+    the GPU and the dict receives data["lab"]; same statistics as with the numpy conversion."""
+    from imagesegmentation_amd import find_surfaces as fs
+    from imagesegmentation_amd import process_surfaces as ps
+    from imagesegmentation_amd.utils import rgb_to_Lab
+    d, c = osd_frame(20)
+    model = fs.find_surface_model("Gauss")
+    a = model((d, c, None))
+    b = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in a.items()}
+    b["lab"] = rgb_to_Lab(c)
+    ps.extract_information_from_surface_data_and_preprocess_surfaces(a, None)
+    ps.extract_information_from_surface_data_and_preprocess_surfaces(b, None)
+    assert np.abs(a["lab"] - b["lab"]).max() <= 1e-10
+    for k in ("surfaces", "avg_pos", "counts", "centroids", "hist_color", "hist_angle", "border_centers", "depth_extend", "planes",
+              "depth_extend_distances"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert a["neighbors"] == b["neighbors"]
