@@ -734,8 +734,9 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     const FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st};
     if (P.mode == 1) return launch_roll_table(2, channel_class, L);
     if (!uniform) return launch_roll_table(1, channel_class, L);
-    // r = 7 keeps the tile with its whole halo in LDS (no step barriers, no half-idle first and last window row:
-    // 44 against 53 us per 640x480 update); every other radius rolls the window through a 16-row ring
+    // r = 7 keeps the tile with its whole halo in LDS (no step barriers, no half-idle first and last window row); a
+    // rolling r = 7 instance at three blocks per CU measured the same 44.7 us per 640x480 update, so the older kernel
+    // stays.  Every other radius rolls the window through a 16-row ring.
     if (g.r == 7) return launch_fused_r7_uniform(channel_class, L);
     return launch_roll_uniform(channel_class, L);
 }

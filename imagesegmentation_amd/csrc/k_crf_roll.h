@@ -143,8 +143,13 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
     }
 }
 
+// blocks per CU the kernel is compiled for: three where the ring of three blocks fits the CU's 160 KB of LDS (the
+// kernel needs no more than the 168 registers that leaves a lane), else two
+template <int R>
+constexpr int roll_blocks_per_cu() { return (R > 0 && (FTW + 2 * R) * RING * 56 + 6 * 1024 <= 160 * 1024 / 3) ? 3 : 2; }
+
 template <int R, int NCH, int MODE, bool UNIFORM>
-__global__ __launch_bounds__(256, 2) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
+__global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
                                                             int nframes, unsigned *__restrict__ queue)
 {
@@ -415,8 +420,9 @@ hipError_t launch_roll_t(const FusedLaunch &L)
     if (!L.queue) return hipErrorInvalidValue;
     hipError_t qe = hipMemsetAsync(L.queue, 0, kCrfQueueBytes, L.st);
     if (qe != hipSuccess) return qe;
-    const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, two per CU
-    dim3 grid(nblk < 512u ? nblk : 512u);
+    const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, as many as the chip holds at once
+    const unsigned resident = 256u * roll_blocks_per_cu<R>();
+    dim3 grid(nblk < resident ? nblk : resident);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue);
     return hipGetLastError();
 }
