@@ -27,6 +27,7 @@ SIGNATURES = {
     "fs_set_gauss_params": (_i, [_vp, _vp]),
     "fs_set_lr_params": (_i, [_vp, _vp]),
     "fs_set_kernel_size": (_i, [_vp, _i]),
+    "fs_set_max_batch": (_i, [_vp, _i]),
     "fs_set_stream": (_i, [_vp, _vp]),
     "fs_use_own_stream": (_i, [_vp]),
     "fs_stream": (_vp, [_vp]),
@@ -189,6 +190,11 @@ class Context:
         self._check(self._lib.fs_set_kernel_size(self._h, int(r)))
         self.kernel_size = int(r)
 
+    def set_max_batch(self, max_batch):
+        """Grow the context in place (handles held elsewhere stay valid)."""
+        self._check(self._lib.fs_set_max_batch(self._h, int(max_batch)))
+        self.max_batch = max(self.max_batch, int(max_batch))
+
     def set_view_angles(self, view_x, view_y):
         self._check(self._lib.fs_set_view_angles(self._h, float(view_x), float(view_y)))
 
@@ -247,15 +253,18 @@ class Context:
         res = [ang, vec, pts] + ([raw] if want_raw else [])
         return [a[0] for a in res] if single else res
 
-    def patches(self, smoothed, want_curvature=False):
+    def patches(self, smoothed, want_curvature=False, want_mask=False):
+        """-> [patches, depth_edges] (+ [curvature scores, curvature mask] with want_curvature, which evaluates every
+        score with correctly rounded arithmetic; + [curvature mask] with want_mask, which keeps the production path: the
+        approximate score decides wherever it is clear of the threshold)."""
         d, single = self._batch(smoothed)
         d = _arr(d, np.float32)
         n = d.shape[0]
         pat, edg = np.empty((n, self.H, self.W), np.int64), np.empty((n, self.H, self.W), np.int32)
         sc = np.empty((n, self.H, self.W), np.float32) if want_curvature else None
-        cm = np.empty((n, self.H, self.W), np.uint8) if want_curvature else None
+        cm = np.empty((n, self.H, self.W), np.uint8) if (want_curvature or want_mask) else None
         self._check(self._lib.fs_patches(self._h, n, _ptr(d), _ptr(pat), _ptr(edg), _ptr(sc), _ptr(cm)))
-        res = [pat, edg] + ([sc, cm] if want_curvature else [])
+        res = [pat, edg] + ([sc, cm] if want_curvature else ([cm] if want_mask else []))
         return [a[0] for a in res] if single else res
 
     def connected_components(self, mask, min_size_exclusive=0):

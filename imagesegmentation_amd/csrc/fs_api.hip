@@ -532,6 +532,19 @@ int fs_set_kernel_size(fs_ctx *ctx, int kernel_size)
     return ctx->have_params ? build_pos_terms(ctx) : 0;
 }
 
+int fs_set_max_batch(fs_ctx *ctx, int max_batch)
+{
+    if (!ctx) return -1;
+    if (max_batch < 1) return ctx->fail("fs_set_max_batch: need max_batch >= 1");
+    if (set_device(ctx)) return -1;
+    if (max_batch <= ctx->max_batch) return 0;          // buffers only grow
+    FS_HIP(hipStreamSynchronize(ctx->stream));             // kernels in flight still use the buffers this call replaces
+    const int old = ctx->max_batch;
+    ctx->max_batch = max_batch;
+    if (ensure_frame_buffers(ctx)) { ctx->max_batch = old; return -1; }
+    return 0;
+}
+
 int fs_set_stream(fs_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return -1;

@@ -228,10 +228,18 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
     const int tx = threadIdx.x % TW, ty = (threadIdx.x / TW) * 2;
     const int x = x0 + tx, y = y0 + ty;
     if (x >= W || y >= H) return;
-    // Weight of a tap: m = |divide_no_nan(dj - dc, dc)| > 0.3 ? 0 : 1.  The rounded quotient differs
-    // from the exact one by less than one part in 1e7, so comparing |dj - dc| with 0.3 |dc| decides
-    // except in a band of that width around the threshold.  The window is summed with the product
-    // test; a pixel that met the band (about one tap in 1e6) is summed again with the division.
+    // Weight of a tap: m = |divide_no_nan(dj - dc, dc)| > 0.3 ? 0 : 1.  The window is summed with a product
+    // test, q = |fl(dj - dc)| against 0.3f |dc|, instead of the division; a pixel that met the band around the
+    // threshold is summed again with the division.  Why the band suffices: both forms start from the same
+    // rounded difference q.  The reference rounds q / |dc| once (relative error <= 2^-24 = 6.0e-8) before it
+    // compares with 0.3f, so it gates exactly when q / |dc| exceeds 0.3f by more than half an ulp of 0.3f
+    // (5.0e-8 relative): its decision flips somewhere in q in [0.3f |dc|, 0.3f |dc| (1 + 5.0e-8)].  The bounds
+    // lo / hi carry two roundings of their own (the product with |dc| and the product with the band factor,
+    // 1.2e-7 together) and the factors 1 -+ 4e-7 round to 1 - 4.17e-7 and 1 + 3.58e-7, so
+    // hi >= 0.3f |dc| (1 + 2.4e-7) lies above every q at which the reference can still pass a tap and
+    // lo <= 0.3f |dc| (1 - 3.0e-7) below every q at which it can gate one: outside [lo, hi] the product test
+    // and the division agree, with a margin of more than four times the largest error.
+    // tests/test_gpu_predicates.py puts taps within a few ulp of both sides of the threshold.
     // dc == 0: divide_no_nan gives 0 and every weight is 1 (thresholds +inf).
     const float dcA = td[ty + R][tx + R], dcB = td[ty + 1 + R][tx + R];
     const float loA = dcA == 0.0f ? INFINITY : 0.3f * fabsf(dcA) * (1.0f - 4e-7f);
@@ -370,11 +378,21 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
     const float dfy = (ay[r] * dc) * 0.5f;
     // Only the comparison with the threshold leaves this kernel (unless the caller asks for the
     // scores), so the score is first evaluated with the hardware's approximate sqrt and reciprocal
-    // (1 ulp each; the reciprocal of |p_k - p_0| is a reciprocal square root of its square).  Every term (dif1 + dif2_prev) / dif2 - 1 is >= 0 (triangle inequality), so
-    // near the threshold all ratios are <= 1 + threshold and the approximate total (which also shares the
-    // lateral parts of the distances between the directions, another few 1e-7 per term) is within 1e-4
-    // of the correctly rounded one (worst case 80 weighted terms x 8e-7); outside a band of 1e-4 the comparison is decided, inside it
-    // the reference's correctly rounded evaluation is repeated (about one pixel in a thousand).
+    // square root (1 ulp = 1.2e-7 each) and fused multiply-adds, and with the lateral parts of the
+    // distances shared between the directions.
+    // Error of the approximate total against the reference's correctly rounded one: the total is the sum of 80
+    // weighted ratios minus 80 (8 directions x 4 steps, step k counted 5 - k times), every ratio
+    // (dif1 + dif2_prev) / dif2 >= 1 by the triangle inequality.  One approximate ratio differs from the real
+    // value by at most 4.8e-7 relative (dif1: half the 6e-8 of its radicand + 1.2e-7 of v_sqrt; dif2_prev: 6e-8
+    // + 1.5e-7 of its v_rsq + 6e-8 of the product; the sum 6e-8; the v_rsq of the divisor 1.5e-7; the final fma
+    // rounds relative to the small score), the reference's by at most 3.0e-7 (three roundings in each radicand,
+    // two correctly rounded roots, one sum, one division), so the two totals differ by at most
+    // 7.8e-7 x (80 + total).  A wrong decision needs the totals on opposite sides of the threshold 0.0735 with the
+    // approximate one more than the band away from it, i.e. a difference above 1e-4, which the bound allows only
+    // for totals above 45, where both lie far above the threshold.  Inside the band of 1e-4 (about one pixel in a
+    // thousand) the reference's evaluation is repeated.  The additions of the 64 terms themselves round at
+    // 2^-24 of a total of ~0.07: 3e-7 in all.
+    // tests/test_gpu_predicates.py tunes surfaces until their totals sit within 2e-4 of the threshold on both sides.
     if (!scores && !(dc > 0.001f)) {                          // no depth: the mask is 0 whatever the score
         mask[i] = 0;
         return;

@@ -28,6 +28,7 @@ standard_kernel_size = 7                             # find_surfaces.py:23
 div_x, div_y = 4, 4                                  # find_surfaces.py:24
 frames_per_call = 37                                 # frames handed to the GPU per call by find_surfaces_for_indices
 
+# GPU of this process: FS_DEVICE if set (e.g. several ranks sharing one GPU), else the launcher's LOCAL_RANK
 _device = int(os.environ.get("FS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 _contexts = {}
 
@@ -41,12 +42,12 @@ def set_device(index):
 def _context(h, w, kernel_size, max_batch=1, params=None):
     key = (_device, int(h), int(w))
     ctx = _contexts.get(key)
-    if ctx is None or ctx.max_batch < max_batch:
-        if ctx is not None:
-            ctx.close()
+    if ctx is None:
         ctx = _lib.Context(h, w, max_batch=max_batch, device=_device, kernel_size=kernel_size, params=params)
         ctx.set_view_angles(viewing_angle_x, viewing_angle_y)
         _contexts[key] = ctx
+    elif ctx.max_batch < max_batch:
+        ctx.set_max_batch(max_batch)            # grows in place: contexts handed out earlier stay valid
     if ctx.kernel_size != kernel_size:
         ctx.set_kernel_size(kernel_size)
     if params is not None:

@@ -46,7 +46,7 @@ def run_sharded(image_indices, process, rank=None, world=None, gather=True):
 def find_surfaces_for_indices_sharded(image_indices, mode="Gauss", kernel_size=7, save_data=True):
     """find_surfaces_for_indices over this rank's shard on GPU LOCAL_RANK."""
     from . import find_surfaces as fs
-    fs.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    fs.set_device(int(os.environ.get("FS_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
 
     def process(indices):
         fs.find_surfaces_for_indices(indices, mode=mode, kernel_size=kernel_size, save_data=save_data)

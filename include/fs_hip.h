@@ -54,6 +54,10 @@ int fs_set_lr_params(fs_ctx *ctx, const float params[7]);
  * (find_surfaces.py:23, 291, 497); default 7, at most 15. */
 int fs_set_kernel_size(fs_ctx *ctx, int kernel_size);
 
+/* Raises the number of frames one call may process (the context's buffers grow; a smaller value changes nothing).  The
+ * handle stays valid, unlike destroying the context and creating a larger one.  No counterpart in the reference. */
+int fs_set_max_batch(fs_ctx *ctx, int max_batch);
+
 /* Use the caller's HIP stream (a hipStream_t passed as void*) instead of the context's own, so that the
  * "_dev" entry points are ordered with the caller's other work on that stream.  A NULL handle is HIP's legacy
  * default stream (what torch.cuda.current_stream().cuda_stream is unless the caller made a stream current).
