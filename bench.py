@@ -112,6 +112,8 @@ def executed_work(ctx, depth, S, r):
     -> executed flops and compact Q bytes (planes a tile reads for its own pixels + planes it writes) per frame-update."""
     n, H, W = depth.shape
     listed, (th, tw) = ctx.tile_labels(n)
+    if (listed < 0).any() or (listed > 512).any():
+        raise RuntimeError("fs_get_tile_labels returned counts outside [0, 512]")
     ty, tx = listed.shape[1:]
     pad = np.zeros((n, ty * th, tx * tw), bool)
     pad[:, :H, :W] = depth != 0

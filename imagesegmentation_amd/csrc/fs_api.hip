@@ -603,10 +603,11 @@ int fs_get_tile_labels(fs_ctx *ctx, int n, int32_t *listed, int *tiles_x, int *t
     if (tile_w) *tile_w = 32;
     if (tile_h) *tile_h = th;
     if (listed) {
-        // word 0 of every tile record
-        const size_t pitch = crf_tile_rec_ints() * sizeof(int32_t);
-        FS_HIP(hipMemcpy2DAsync(listed, sizeof(int32_t), ctx->tile_recs.p, pitch, sizeof(int32_t), (size_t)n * tx * ty,
-                                hipMemcpyDeviceToHost, ctx->stream));
+        const int total = n * tx * ty;
+        FS_HIP(ctx->st_pool.ensure((size_t)total * sizeof(int32_t)));
+        launch_crf_tile_counts(ctx->tile_recs.as<int32_t>(), ctx->st_pool.as<int32_t>(), total, ctx->stream);
+        FS_HIP(hipGetLastError());
+        FS_HIP(hipMemcpyAsync(listed, ctx->st_pool.p, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;

@@ -171,6 +171,8 @@ void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hi
 // patch labels present within `grow` pixels of every tile_w x tile_h tile, for n frames; max_active[n] must be zeroed
 void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
                             int32_t *max_active, hipStream_t st);
+// number of listed labels of `total` consecutive tile records -> out[total] (device pointers)
+void launch_crf_tile_counts(const int32_t *recs, int32_t *out, int total, hipStream_t st);
 // mode bits for launch_crf_iter
 enum { CRF_LAST = 1, CRF_FIRST = 2 };
 // one mean-field update of nframes frames whose per-tile channel count fits `channel_class`

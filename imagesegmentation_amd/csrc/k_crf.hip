@@ -690,6 +690,17 @@ void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int til
                        total, recs, max_active);
 }
 
+// word 0 (number of listed labels) of every tile record, gathered into a dense array
+__global__ __launch_bounds__(256) void crf_tile_counts_kernel(const int32_t *__restrict__ recs, int32_t *__restrict__ out, int total)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < total) out[t] = recs[(size_t)t * TILE_REC];
+}
+void launch_crf_tile_counts(const int32_t *recs, int32_t *out, int total, hipStream_t st)
+{
+    hipLaunchKernelGGL(crf_tile_counts_kernel, dim3((total + 255) / 256), dim3(256), 0, st, recs, out, total);
+}
+
 // tile height of the fused kernels (tile width 32); 0 if the window is too large for them
 int crf_fused_tile_height(int r) { return r >= 1 && r <= kMaxRadius ? 16 : 0; }
 void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y)

@@ -11,7 +11,8 @@ Two ways through the stage exist, with identical results:
   * the operator path: the four objects get_GPU_models() returns can be called one by one
     exactly as the reference's find_surfaces() body does (smoothing, normals, patches,
     conv_crf.predict on 4x4 tiles); find_surfaces() takes that route when handed a plain
-    4-tuple of callables that does not come from get_GPU_models().
+    4-tuple of callables that does not come from get_GPU_models().  conv_crf_Gauss.predict carries at most 128
+    label channels per call (fs_crf_step), so that route stops at 127 surfaces per frame; the fused path carries 512.
 """
 import os
 

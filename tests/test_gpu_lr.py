@@ -59,7 +59,8 @@ def test_find_surfaces_lr_fused(oracle, params):
         if dis.any():
             q = np.sort(ref["q_final"][dis], axis=-1)
             assert ((q[:, -1] - q[:, -2]) <= 1e-5 * q[:, -1]).all(), name
-        assert dis.mean() <= 0.005
+        print("label disagreement:", float(dis.mean()))
+        assert dis.mean() <= 0.001
         if params == "soft":
             assert len(np.unique(ref["surfaces"])) > 3        # a non-trivial labelling
 
@@ -79,4 +80,5 @@ def test_mirror_lr_mode(oracle):
     assert np.array_equal(step["surfaces"], ref["surfaces"])
     # and back to the Gaussian similarity on the same context
     gauss = fs.find_surface_model("Gauss")((depth, rgb, None))
-    assert (gauss["surfaces"] != g["surfaces"]).mean() <= 0.005
+    print("label disagreement:", float((gauss["surfaces"] != g["surfaces"]).mean()))
+    assert (gauss["surfaces"] != g["surfaces"]).mean() <= 0.001

@@ -66,7 +66,8 @@ def test_operator_path_equals_fused_path(oracle):
     assert fused["num_surfaces"] == stepwise["num_surfaces"] == int(g["num_surfaces"])
     assert _ties_only(stepwise["surfaces"], g["surfaces"], g["q_final"])
     assert _ties_only(fused["surfaces"], g["surfaces"], g["q_final"])
-    assert (fused["surfaces"] != stepwise["surfaces"]).mean() <= 0.005
+    print("label disagreement:", float((fused["surfaces"] != stepwise["surfaces"]).mean()))
+    assert (fused["surfaces"] != stepwise["surfaces"]).mean() <= 0.0015
 
 
 def test_find_surfaces_for_indices_writes_the_reference_files(tmp_path, monkeypatch):
@@ -101,7 +102,8 @@ def test_apply_crf_matches_oracle(oracle):
     out = pp.get_postprocessing_model()(data)["final_surfaces"]
     assert out.dtype == np.int64 and out.shape == final.shape
     assert _ties_only(out, ref, Q)
-    assert (out != ref).mean() <= 0.005
+    print("label disagreement:", float((out != ref).mean()))
+    assert (out != ref).mean() <= 0.0015
     assert pp.get_postprocessing_model(do_post_processing=False)(data) is data
 
 
@@ -116,7 +118,8 @@ def test_other_window_radii(oracle, r):
         ref = oracle.find_surfaces(d[i], c[i], oracle.gauss_params(), r=r, want_q=True)
         assert np.array_equal(got["patches"][i], ref["patches"])
         assert _ties_only(got["surfaces"][i], ref["surfaces"], ref["q_final"]), r
-        assert (got["surfaces"][i] != ref["surfaces"]).mean() <= 0.005
+        print("label disagreement:", float((got["surfaces"][i] != ref["surfaces"]).mean()))
+        assert (got["surfaces"][i] != ref["surfaces"]).mean() <= 0.0015
 
 
 def test_frame_1280x960(oracle):
@@ -133,10 +136,11 @@ def test_frame_1280x960(oracle):
     assert np.array_equal(got["patches"], ref["patches"])
     assert np.array_equal(got["depth_edges"], ref["depth_edges"])
     # ~300 label channels: regions no patch reaches within 3 updates hold ~300 equal probabilities, and
-    # which one the argmax picks is rounding noise in both implementations -- ties only, >= 99.5 % equal
+    # which one the argmax picks is rounding noise in both implementations -- ties only, >= 99.7 % equal
     assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
     assert got["num_surfaces"] > 128
-    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.005
+    print("label disagreement:", float((got["surfaces"] != ref["surfaces"]).mean()))
+    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.003        # measured 0.25 %, every one of them a tie
 
 
 def test_batch_and_shard_invariance():
@@ -181,7 +185,8 @@ def test_position_dependent_weights(oracle):
     ref = oracle.find_surfaces(g["depth"], g["rgb"], p, want_q=True)
     assert np.array_equal(got["patches"], ref["patches"])
     assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
-    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.005
+    print("label disagreement:", float((got["surfaces"] != ref["surfaces"]).mean()))
+    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.003         # measured 0.20 %, ties only
     assert (ref["surfaces"] != g["surfaces"]).any()      # the parameters matter
 
 

@@ -179,7 +179,8 @@ def test_find_surfaces_small(small_ctx, oracle):
         assert np.abs(got["angles"][i] - ref["angles"]).max() <= 4e-6
         agree, ties_only = _agreement(got["surfaces"][i], ref["surfaces"], ref["q_final"])
         assert ties_only, "label disagreement that is not a numerical tie"
-        assert agree >= 0.995
+        print("label agreement:", agree)
+        assert agree >= 0.9985      # 96x128 frames: 12 pixels are 0.1 %; measured 99.90 - 99.94 %, ties only
 
 
 @pytest.mark.parametrize("index", [0, 57])

@@ -14,7 +14,8 @@ trace() {   # name, bench args...
       > "$out/$name/bench_under_rocprof.json" 2> "$out/$name/stats.log" || { echo "$name: stats run failed"; tail -5 "$out/$name/stats.log"; exit 1; }
   echo "$name done"
 }
-trace osd --steps 5 --warmup 2
+trace osd --steps 5 --warmup 2 --no-host-leg
+trace osd_hostbuf --host-buffers --steps 5 --warmup 2
 trace m1280_s32_r7 --workload mosaic1280 --labels 32 --kernel-size 7 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s32_r10 --workload mosaic1280 --labels 32 --kernel-size 10 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s64_r15 --workload mosaic1280 --labels 64 --kernel-size 15 --steps 3 --warmup 1 --no-host-leg
@@ -30,8 +31,11 @@ pmc() {     # name, counters, bench args...
 pmc osd_fetch FETCH_SIZE --frames 16
 pmc osd_write WRITE_SIZE --frames 16
 pmc osd_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" --frames 16
+pmc osd_grbm "GRBM_GUI_ACTIVE GRBM_COUNT" --frames 16
 pmc r10_fetch FETCH_SIZE --workload mosaic1280 --labels 32 --kernel-size 10 --frames 4
 pmc r10_write WRITE_SIZE --workload mosaic1280 --labels 32 --kernel-size 10 --frames 4
 pmc r10_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" --workload mosaic1280 --labels 32 --kernel-size 10 --frames 4
+pmc r10_grbm "GRBM_GUI_ACTIVE GRBM_COUNT" --workload mosaic1280 --labels 32 --kernel-size 10 --frames 4
+pmc r15_grbm "GRBM_GUI_ACTIVE GRBM_COUNT" --workload mosaic1280 --labels 64 --kernel-size 15 --frames 4
 pmc r15_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" --workload mosaic1280 --labels 64 --kernel-size 15 --frames 4
 find "$out" -name '*kernel_stats.csv' | head -8
