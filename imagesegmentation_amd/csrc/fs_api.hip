@@ -212,7 +212,7 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->cc_newid.ensure(n * N * 4));
     FS_HIP(ctx->cc_blocksum.ensure(n * cc_blocks_per_image(ctx->H, ctx->W) * 4));
     FS_HIP(ctx->counts.ensure(2 * n * 4));
-    FS_HIP(ctx->crf_queue.ensure(kCrfQueueBytes));
+    FS_HIP(ctx->crf_queue.ensure(kCrfQueueSlots * kCrfQueueBytes));
     FS_HIP(ctx->curv_todo.ensure(curvature_todo_ints((int)n, curv_todo_cap(ctx)) * sizeof(int32_t)));
     if (crf_fused_tile_height(ctx->r)) {
         int tx, ty;
@@ -389,6 +389,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
         launch_crf_pack_features(d_depth, d_rgb, angle_features_ready ? nullptr : d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N,
                                  ctx->params, ctx->stream);
     }
+    int queue_slot = kCrfQueueSlots;                    // tile queues: one zeroed slot per launch, all cleared by one memset
     for (int gi = 0; gi < ngroups; ++gi) {
         const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
         if (!fused) {
@@ -404,7 +405,12 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             ScopedTimer t(ctx, G_ITER);
             for (const Launch &l : launches[(size_t)gi * iterations + it]) {
                 const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
-                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, ctx->crf_queue.as<unsigned>(), ctx->stream)
+                if (fused && queue_slot == kCrfQueueSlots) {
+                    FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
+                    queue_slot = 0;
+                }
+                unsigned *queue = ctx->crf_queue.as<unsigned>() + (fused ? queue_slot++ : 0) * (kCrfQueueBytes / sizeof(unsigned));
+                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream)
                                      : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }

@@ -192,9 +192,11 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
 float crf_angle_feature_scale(const CrfParams &P);
 // CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
 // planes of a tile's listed labels and of its representative are written (see k_crf.hip).
-// tile_queue: kCrfQueueBytes of device memory owned by the caller's context (the launch zeroes it; launches
+// tile_queue: kCrfQueueBytes of zeroed device memory that no other launch in flight uses (the caller keeps
+// kCrfQueueSlots of them and clears them all with one memset; launches
 // that share it must be ordered on one stream).
 constexpr size_t kCrfQueueStride = 128, kCrfQueueBytes = 8 * kCrfQueueStride;
+constexpr int kCrfQueueSlots = 64;
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st);
 

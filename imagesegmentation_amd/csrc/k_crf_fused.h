@@ -34,7 +34,7 @@ namespace {
 // ---------------------------------------------------------------------------
 
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
-// from the staged chunk: acc[k] (a packed pair, one half per pixel) += sum over the window of sim(pixel, neighbour) * Q_neighbour[k].
+// from the staged chunk: acc[i][k] += sum over the window of sim(pixel i, neighbour) * Q_neighbour[k].
 // Both rows are carried as packed pairs, one v_pk_* instruction per operation.  The 2r region rows that
 // lie in both windows are read once for the pair; the topmost row (reached only by row 0) and the
 // bottommost (only by row 1) go through one extra pass together, each half of the pair with its own
@@ -43,7 +43,7 @@ namespace {
 // The relative depth difference divides by (d_p + d_q): a lane whose own depth is 0 may produce
 // NaN here; its result is overridden afterwards (Q[depth == 0]) and never read.
 template <int R, int NQ, int MODE, bool UNIFORM>
-__device__ __forceinline__ void fused_accumulate(f2 (&acc)[8], const float4 *lds4, int plane4, int LW, int trow, int col, int r,
+__device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float4 *lds4, int plane4, int LW, int trow, int col, int r,
                                                  const FusedConsts &K, const float4 *__restrict__ wtab)
 {
     const int kw = 2 * r + 1;
@@ -121,32 +121,21 @@ __device__ __forceinline__ void fused_accumulate(f2 (&acc)[8], const float4 *lds
                  __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
                  __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
         }
-        // acc[k] = (pixel 0, pixel 1) of channel k
-        if (&a == &b) {
-            // shared rows: one neighbour for both pixels, its Q value is one register read by both halves
-            acc[0] = __builtin_elementwise_fma(sv, f2{a.q0.x, a.q0.x}, acc[0]);
-            acc[1] = __builtin_elementwise_fma(sv, f2{a.q0.y, a.q0.y}, acc[1]);
-            acc[2] = __builtin_elementwise_fma(sv, f2{a.q0.z, a.q0.z}, acc[2]);
-            acc[3] = __builtin_elementwise_fma(sv, f2{a.q0.w, a.q0.w}, acc[3]);
+        // acc[i][k]: pixel i, channel k.  Two adjacent channels of one pixel make a packed operation (the similarity of
+        // the pixel in both halves), in the shared rows and in the pass where each pixel has its own neighbour alike.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float sI = i == 0 ? sv.x : sv.y;
+            const float4 q0 = i == 0 ? a.q0 : b.q0, q1 = i == 0 ? a.q1 : b.q1;
+            acc[i][0] = fmaf(sI, q0.x, acc[i][0]);
+            acc[i][1] = fmaf(sI, q0.y, acc[i][1]);
+            acc[i][2] = fmaf(sI, q0.z, acc[i][2]);
+            acc[i][3] = fmaf(sI, q0.w, acc[i][3]);
             if (NQ > 1) {
-                acc[4] = __builtin_elementwise_fma(sv, f2{a.q1.x, a.q1.x}, acc[4]);
-                acc[5] = __builtin_elementwise_fma(sv, f2{a.q1.y, a.q1.y}, acc[5]);
-                acc[6] = __builtin_elementwise_fma(sv, f2{a.q1.z, a.q1.z}, acc[6]);
-                acc[7] = __builtin_elementwise_fma(sv, f2{a.q1.w, a.q1.w}, acc[7]);
-            }
-        } else {
-            // each pixel has its own neighbour: two updates with the other half's similarity zeroed (x + 0 * q = x),
-            // which keeps every Q operand a single register instead of a pair assembled from two
-            const f2 s0 = f2{sv.x, 0.0f}, s1 = f2{0.0f, sv.y};
-            acc[0] = __builtin_elementwise_fma(s1, f2{b.q0.x, b.q0.x}, __builtin_elementwise_fma(s0, f2{a.q0.x, a.q0.x}, acc[0]));
-            acc[1] = __builtin_elementwise_fma(s1, f2{b.q0.y, b.q0.y}, __builtin_elementwise_fma(s0, f2{a.q0.y, a.q0.y}, acc[1]));
-            acc[2] = __builtin_elementwise_fma(s1, f2{b.q0.z, b.q0.z}, __builtin_elementwise_fma(s0, f2{a.q0.z, a.q0.z}, acc[2]));
-            acc[3] = __builtin_elementwise_fma(s1, f2{b.q0.w, b.q0.w}, __builtin_elementwise_fma(s0, f2{a.q0.w, a.q0.w}, acc[3]));
-            if (NQ > 1) {
-                acc[4] = __builtin_elementwise_fma(s1, f2{b.q1.x, b.q1.x}, __builtin_elementwise_fma(s0, f2{a.q1.x, a.q1.x}, acc[4]));
-                acc[5] = __builtin_elementwise_fma(s1, f2{b.q1.y, b.q1.y}, __builtin_elementwise_fma(s0, f2{a.q1.y, a.q1.y}, acc[5]));
-                acc[6] = __builtin_elementwise_fma(s1, f2{b.q1.z, b.q1.z}, __builtin_elementwise_fma(s0, f2{a.q1.z, a.q1.z}, acc[6]));
-                acc[7] = __builtin_elementwise_fma(s1, f2{b.q1.w, b.q1.w}, __builtin_elementwise_fma(s0, f2{a.q1.w, a.q1.w}, acc[7]));
+                acc[i][4] = fmaf(sI, q1.x, acc[i][4]);
+                acc[i][5] = fmaf(sI, q1.y, acc[i][5]);
+                acc[i][6] = fmaf(sI, q1.z, acc[i][6]);
+                acc[i][7] = fmaf(sI, q1.w, acc[i][7]);
             }
         }
     };
@@ -403,11 +392,13 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         }
     }
 
-    f2 acc[NCH][CH];                                        // messages: (pixel 0, pixel 1) per channel slot
+    float acc[NCH][2][CH];                                  // messages: chunk, pixel, channel slot
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int k = 0; k < CH; ++k) acc[c][k] = f2{0.0f, 0.0f};
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[c][i][k] = 0.0f;
 
     const int ns = S - 1;
     const float q_pv = (float)(1.0 / (double)ns), q_other = (float)(1.0 / (double)(ns - 1) * 0.1);
@@ -474,14 +465,14 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     }
 
     if (FS_SKIPFIN) {                              // timing experiments: keep the messages alive without the epilogue
-        f2 t = f2{0.0f, 0.0f};
+        float t = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) t += acc[c / CH][c % CH];
-        if (t.x + t.y == 12345.678f) const_cast<float *>(d.Qin)[0] = t.x;
+        for (int c = 0; c < NCH * CH; ++c) t += acc[c / CH][0][c % CH] + acc[c / CH][1][c % CH];
+        if (t == 12345.678f) const_cast<float *>(d.Qin)[0] = t;
     } else {
         f2 m[NCH * CH];
 #pragma unroll
-        for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][c % CH];
+        for (int c = 0; c < NCH * CH; ++c) m[c] = f2{acc[c / CH][0][c % CH], acc[c / CH][1][c % CH]};     // the epilogue works on pixel pairs
         finish_pair_compact<NCH * CH>(m, s_list, s_tab, d, S, Ni, p, own, ok, valid, weight, last);
     }
     if (threadIdx.x == 0) s_ticket = next_ticket;     // every lane read the current ticket several barriers ago
@@ -503,8 +494,6 @@ hipError_t launch_fused_t(const FusedLaunch &L)
     // queue of its XCD until it is empty.  A block that ends and a new one that takes its place cost the CU
     // several microseconds with half its waves missing; a block that just takes the next tile does not.
     if (!L.queue) return hipErrorInvalidValue;
-    hipError_t qe = hipMemsetAsync(L.queue, 0, kCrfQueueBytes, L.st);
-    if (qe != hipSuccess) return qe;
     const unsigned nblk = (tiles + 7u) / 8u * 8u;
     static const unsigned max_blocks = [] {                  // FS_CRF_BLOCKS: experiments with fewer or more resident blocks
         const char *e = getenv("FS_CRF_BLOCKS");

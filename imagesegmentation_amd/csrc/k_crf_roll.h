@@ -418,8 +418,6 @@ hipError_t launch_roll_t(const FusedLaunch &L)
     if (hipError_t e = allowed.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     const unsigned tiles = (unsigned)((g.Wi + FTW - 1) / FTW) * ((g.Hi + RING - 1) / RING) * L.nframes;
     if (!L.queue) return hipErrorInvalidValue;
-    hipError_t qe = hipMemsetAsync(L.queue, 0, kCrfQueueBytes, L.st);
-    if (qe != hipSuccess) return qe;
     const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, as many as the chip holds at once
     const unsigned resident = 256u * roll_blocks_per_cu<R>();
     dim3 grid(nblk < resident ? nblk : resident);
