@@ -213,3 +213,40 @@ def test_degenerate_frames(oracle):
     with pytest.raises(RuntimeError):
         with Context(H, W, max_batch=1) as ctx:
             ctx.find_surfaces_batch(d[:2], c[:2])     # batch larger than max_batch
+
+
+@pytest.mark.parametrize("r,shape", [(10, (50, 70)), (15, (50, 70)), (15, (24, 40)), (4, (37, 90))])
+def test_rolling_window_on_ragged_and_tiny_frames(oracle, r, shape):
+    """Window radii other than 7 on frames whose sides are no multiples of the 32 x 16 tiles, and on a frame smaller than
+    the 31 x 31 window itself (every region row of every tile then crosses the frame border)."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = shape
+    d, c = make_batch([51, 52], H, W)
+    d[1, : H // 2] = 0                                   # the upper half without depth: whole tiles are skipped
+    with Context(H, W, max_batch=2, kernel_size=r) as ctx:
+        got = ctx.find_surfaces_batch(d, c)
+    for i in range(2):
+        ref = oracle.find_surfaces(d[i], c[i], oracle.gauss_params(), r=r, want_q=True)
+        assert got["num_surfaces"][i] == ref["num_surfaces"]
+        assert np.array_equal(got["patches"][i], ref["patches"])
+        assert _ties_only(got["surfaces"][i], ref["surfaces"], ref["q_final"]), (r, shape, i)
+        print("label disagreement:", float((got["surfaces"][i] != ref["surfaces"]).mean()))
+        assert (got["surfaces"][i] != ref["surfaces"]).mean() <= 0.003
+
+
+def test_position_dependent_weights_with_a_larger_window(oracle):
+    """The per-offset weight table in the rolling-window kernel (r = 10)."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    d, c = make_batch([61], 96, 128)
+    p = oracle.gauss_params().copy()
+    p[4:7] = [3.0, 5.0, 2.0]
+    p[3] = 0.05
+    with Context(96, 128, kernel_size=10, params=p) as ctx:
+        got = ctx.find_surfaces_batch(d[0], c[0])
+    ref = oracle.find_surfaces(d[0], c[0], p, r=10, want_q=True)
+    assert np.array_equal(got["patches"], ref["patches"])
+    assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
+    print("label disagreement:", float((got["surfaces"] != ref["surfaces"]).mean()))
+    assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.003
