@@ -181,10 +181,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FS_DEVICE / FS_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with one card (all ranks share it and
+    # synchronise over gloo; RCCL does not take two ranks on one GPU).  Unset on a real node: rank i -> GPU i over RCCL.
+    device_index = int(os.environ.get("FS_DEVICE", local_rank))
+    backend = os.environ.get("FS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     big = args.workload in ("synthetic1280", "mosaic1280")
     frames = args.frames or (16 if big else 100 if args.workload == "stream640" else 111)
@@ -193,7 +200,7 @@ def main():
     n, H, W = depth.shape
 
     from imagesegmentation_amd._lib import Context, pinned_empty
-    ctx = Context(H, W, max_batch=n, device=local_rank, kernel_size=args.kernel_size)
+    ctx = Context(H, W, max_batch=n, device=device_index, kernel_size=args.kernel_size)
     # one stream for torch's copies and the library's kernels: a side stream made current, handed to the library
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
@@ -243,7 +250,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.set_timing(0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -299,7 +306,7 @@ def main():
                                  "staged channel); algorithmic_tflops prices all S channels of every pixel and may exceed the peak "
                                  "because the kernel carries only the labels near a tile; busy = VALU-issue share of the kernel's "
                                  "duration from the committed SQ counters"}}
-        if not host_main and not args.no_host_leg:
+        if not host_main and not args.no_host_leg and world == 1:
             # the same stage host buffer to host buffer (page-locked): inputs 1.5 MB and the six output arrays 15.8 MB per
             # 640x480 frame cross PCIe inside the timed region
             step_host()
@@ -311,10 +318,10 @@ def main():
             torch.cuda.synchronize(dev)
             hdt = time.perf_counter() - t1
             per_frame_bytes = N * (2 + 3) + N * (8 + 12 + 12 + 8 + 4 + 8)
-            out["value_host_buffers"] = {"value": world * n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
+            out["value_host_buffers"] = {"value": n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
                                          "bytes_per_frame": per_frame_bytes, "pcie_gbs": hs * n * per_frame_bytes / hdt / 1e9,
-                                         "note": "page-locked host arrays in, six page-locked output arrays back; measured on rank 0 "
-                                                 "after the headline loop, times the world size"}
+                                         "note": "page-locked host arrays in, six page-locked output arrays back; measured after the "
+                                                 "headline loop, N = 1 only (--workload stream640 is the N > 1 form)"}
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(depth, rgb, r)
             out["cpu_baseline_b0"] = cpu_baseline_b0(depth, rgb, r)
