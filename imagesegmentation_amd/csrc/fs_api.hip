@@ -38,11 +38,14 @@ struct fs_ctx {
     DevBuf cc_parent, cc_count, cc_newid, cc_blocksum;
     // CRF buffers (one frame in flight)
     DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
-    std::vector<CrfFrameDesc> descs_host;
-    DevBuf crf_queue;                  // tile queue of the fused CRF update
+    HostBuf descs_host;                // page-locked staging of the frame descriptors; descs_copied: its last upload
+    hipEvent_t descs_copied = nullptr;
+    DevBuf crf_queue;                  // tile queues of the fused CRF update
+    bool queue_clean = false;          // all queue slots are zero and no launch has been given one since
     DevBuf curv_todo;                  // pixels whose curvature test needs the correctly rounded evaluation
+    bool todo_clean = false;           // its per-frame counters are zero (the chain of kernels leaves them so)
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
-    std::vector<int32_t> counts_host;  // nlabels[0..n) then max_active[0..n)
+    HostBuf counts_host;               // page-locked: nlabels[0..n) then max_active[0..n)
     // per-surface statistics (one frame in flight)
     DevBuf st_in, st_work, st_scratch, st_out, st_pool, st_descs, st_lin, st_lab;
     std::vector<StatsFrame> st_descs_host;
@@ -214,6 +217,9 @@ int ensure_frame_buffers(fs_ctx *ctx)
     FS_HIP(ctx->counts.ensure(2 * n * 4));
     FS_HIP(ctx->crf_queue.ensure(kCrfQueueSlots * kCrfQueueBytes));
     FS_HIP(ctx->curv_todo.ensure(curvature_todo_ints((int)n, curv_todo_cap(ctx)) * sizeof(int32_t)));
+    ctx->todo_clean = false;           // new memory, or another layout (the lists follow max_batch counters)
+    ctx->queue_clean = false;
+    FS_HIP(ctx->counts_host.ensure(2 * n * sizeof(int32_t)));
     if (crf_fused_tile_height(ctx->r)) {
         int tx, ty;
         crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
@@ -243,26 +249,32 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
     const float threshold = (float)(0.007003343675404672 * 10.5);   // find_surfaces.py:229
     {
         ScopedTimer t(ctx, G_STENCIL);
-        launch_curvature_mask(d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), threshold, d_curv, d_scores, ctx->curv_todo.as<int32_t>(),
-                              curv_todo_cap(ctx), n, H, W, ctx->stream);
-        launch_majority_edges(d_curv, d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), 3.0f, ctx->mask.as<uint8_t>(), d_edges, n, H, W, ctx->stream);
+        // the list counters of the curvature pass are zeroed by the majority pass that follows it, so that a call
+        // needs no memset of its own once the first one has run
+        const bool used = launch_curvature_mask(d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), threshold, d_curv, d_scores,
+                                                ctx->curv_todo.as<int32_t>(), curv_todo_cap(ctx), ctx->max_batch, ctx->todo_clean, n, H, W,
+                                                ctx->stream);
+        if (used) ctx->todo_clean = false;
+        launch_majority_edges(d_curv, d_smoothed, ctx->ax.as<float>(), ctx->ay.as<float>(), 3.0f, ctx->mask.as<uint8_t>(), d_edges,
+                              used ? ctx->curv_todo.as<int32_t>() : nullptr, n, H, W, ctx->stream);
+        if (used) ctx->todo_clean = true;
     }
+    int32_t *maxa = ctx->counts.as<int32_t>() + n;
     {
         ScopedTimer t(ctx, G_CC);
-        launch_connected_components(ctx->mask.as<uint8_t>(), cc_work(ctx), 20, d_patches64, d_patches32, n, H, W, ctx->stream);
+        CcWork w = cc_work(ctx);
+        if (read_counts) w.clear = maxa;        // the per-frame maxima the tile scan accumulates into start at zero
+        launch_connected_components(ctx->mask.as<uint8_t>(), w, 20, d_patches64, d_patches32, n, H, W, ctx->stream);
     }
     FS_HIP(hipGetLastError());
     if (read_counts) {
         // per-tile active patch labels for the CRF (needs only the patches), then one readback of
         // label counts and per-frame maxima
-        int32_t *maxa = ctx->counts.as<int32_t>() + n;
-        FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
         if (const int th = crf_fused_tile_height(ctx->r)) {
             ScopedTimer t(ctx, G_INIT);
             launch_crf_tile_active(d_patches32, n, H, W, 32, th, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
         }
-        ctx->counts_host.resize(2 * n);
-        FS_HIP(hipMemcpyAsync(ctx->counts_host.data(), ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(hipMemcpyAsync(ctx->counts_host.p, ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;
@@ -294,7 +306,7 @@ constexpr int kPipeChunk = 16;  // frames per upload / compute / download step o
 // frames of one kernel variant (channel class) share a launch.
 int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, const float *d_angles,
                   const int32_t *d_labels32, const int *S, const int *max_active, int iterations, int64_t *d_surfaces,
-                  bool angle_features_ready = false)
+                  bool features_packed = false)
 {
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
@@ -332,8 +344,13 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     FS_HIP(ctx->qb.ensure(qmax * sizeof(float)));
 
     // descriptors: [group][iteration][frames of the group ordered by channel class]
-    std::vector<CrfFrameDesc> &dh = ctx->descs_host;
-    dh.assign((size_t)n * iterations, CrfFrameDesc{});
+    // page-locked, so that the upload is a plain DMA transfer; the previous upload must have left it
+    const size_t ndesc = (size_t)n * iterations;
+    if (ctx->descs_copied) FS_HIP(hipEventSynchronize(ctx->descs_copied));
+    else FS_HIP(hipEventCreateWithFlags(&ctx->descs_copied, hipEventDisableTiming));
+    FS_HIP(ctx->descs_host.ensure(ndesc * sizeof(CrfFrameDesc)));
+    CrfFrameDesc *dh = ctx->descs_host.as<CrfFrameDesc>();
+    std::fill(dh, dh + ndesc, CrfFrameDesc{});
     struct Launch { size_t first; int count, cls; };
     std::vector<std::vector<Launch>> launches((size_t)ngroups * iterations);
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -380,16 +397,18 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             }
         }
     }
-    FS_HIP(ctx->descs.ensure(dh.size() * sizeof(CrfFrameDesc)));
-    FS_HIP(hipMemcpyAsync(ctx->descs.p, dh.data(), dh.size() * sizeof(CrfFrameDesc), hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx->descs.ensure(ndesc * sizeof(CrfFrameDesc)));
+    FS_HIP(hipMemcpyAsync(ctx->descs.p, dh, ndesc * sizeof(CrfFrameDesc), hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipEventRecord(ctx->descs_copied, ctx->stream));
     const CrfFrameDesc *dd = ctx->descs.as<CrfFrameDesc>();
     const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
-    if (fused) {
+    if (fused && !features_packed) {
         ScopedTimer t(ctx, G_SIM);
-        launch_crf_pack_features(d_depth, d_rgb, angle_features_ready ? nullptr : d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N,
-                                 ctx->params, ctx->stream);
+        launch_crf_pack_features(d_depth, d_rgb, d_angles, ctx->featA.p, ctx->featB.p, (size_t)n * N, ctx->params, ctx->stream);
     }
-    int queue_slot = kCrfQueueSlots;                    // tile queues: one zeroed slot per launch, all cleared by one memset
+    // tile queues: one zeroed slot per launch, all cleared by one memset (which the caller may have issued already)
+    int queue_slot = ctx->queue_clean ? 0 : kCrfQueueSlots;
+    ctx->queue_clean = false;
     for (int gi = 0; gi < ngroups; ++gi) {
         const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
         if (!fused) {
@@ -480,6 +499,9 @@ void fs_destroy(fs_ctx *ctx)
     if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
     for (hipEvent_t e : ctx->pipe_events) (void)hipEventDestroy(e);
+    if (ctx->descs_copied) (void)hipEventDestroy(ctx->descs_copied);
+    ctx->descs_host.release();
+    ctx->counts_host.release();
     delete ctx;
 }
 
@@ -805,15 +827,26 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
         launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, fused_crf ? ctx->featB.p : nullptr,
                             crf_angle_feature_scale(ctx->params), n, H, W, ctx->stream);
     }
+    if (fused_crf) {
+        // what the CRF needs and the label counts do not decide goes in front of the read-back of those counts: the
+        // other half of the feature records, and clean tile queues
+        {
+            ScopedTimer t(ctx, G_SIM);
+            launch_crf_pack_features(d_depth, d_rgb, nullptr, ctx->featA.p, ctx->featB.p, (size_t)n * ctx->N(), ctx->params, ctx->stream);
+        }
+        FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
+        ctx->queue_clean = true;
+    }
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
                     ctx->curv.as<uint8_t>(), true))                                                            // :513
         return -1;
     std::vector<int> S(n), maxa(n);
+    const int32_t *counts = ctx->counts_host.as<int32_t>();
     for (int i = 0; i < n; ++i) {
-        const int ns = ctx->counts_host[i] + 1;                                                                // :514
+        const int ns = counts[i] + 1;                                                                          // :514
         if (num_surfaces) num_surfaces[i] = ns;
         S[i] = ns + 1;
-        maxa[i] = ctx->counts_host[n + i];
+        maxa[i] = counts[n + i];
     }
     if (run_crf_batch(ctx, n, d_depth, d_rgb, angles, ctx->patches32.as<int32_t>(), S.data(), maxa.data(), 3, surfaces, fused_crf))   // :515-532
         return -1;
@@ -917,10 +950,9 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
     if (const int th = crf_fused_tile_height(ctx->r))
         launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, 32, th, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
-    ctx->counts_host.resize(2 * n);
-    FS_HIP(hipMemcpyAsync(ctx->counts_host.data() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->counts_host.as<int32_t>() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int> ma(ctx->counts_host.begin() + n, ctx->counts_host.end());
+    std::vector<int> ma(ctx->counts_host.as<int32_t>() + n, ctx->counts_host.as<int32_t>() + 2 * n);
     if (run_crf_batch(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), ctx->angles.as<float>(), ctx->patches32.as<int32_t>(),
                       S.data(), ma.data(), 1, ctx->surfaces64.as<int64_t>()))
         return -1;

@@ -33,6 +33,22 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Grow-only page-locked host buffer owned by a context (contents are lost when it grows).
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 // Parameters of the Gaussian pixel-similarity function and of the mean-field
 // update (find_surfaces.py:221-226, 291, 339-341, 352-361), as the kernels use them.
 struct CrfParams {
@@ -61,13 +77,18 @@ void launch_normals(const float *D, const float *tanx, const float *tany, float 
 // feat (may be null): float2 [n][H][W] that receives feat_scale * angles, the angle half of the CRF feature records
 void launch_angle_filter(const float *raw_angles, const float *D, float *angles, void *feat, float feat_scale, int n, int H, int W,
                          hipStream_t st);
-// todo: curvature_todo_ints(n, todo_cap) ints of work space for the pixels whose threshold test needs the
-// correctly rounded evaluation (a second, small kernel handles them); may be null
-void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
-                           float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st);
-size_t curvature_todo_ints(int n, int todo_cap);
+// todo: curvature_todo_ints(todo_frames, todo_cap) ints of work space for the pixels whose threshold test needs the
+// correctly rounded evaluation (a second, small kernel handles them); may be null.  Its first todo_frames words
+// are per-frame counters that must be zero when the kernels start: todo_zeroed says they are, otherwise a memset
+// precedes the kernels.  Returns whether the counters were used (and are now non-zero until somebody clears them:
+// launch_majority_edges does, given the pointer).
+bool launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
+                           float *scores, int32_t *todo, int todo_cap, int todo_frames, bool todo_zeroed, int n, int H, int W,
+                           hipStream_t st);
+size_t curvature_todo_ints(int frames, int todo_cap);
+// clear (may be null): n words zeroed on the way, one per frame
 void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
-                           uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st);
+                           uint8_t *mask, int32_t *edges, int32_t *clear, int n, int H, int W, hipStream_t st);
 // connected components (k_cc.hip)
 struct CcWork {
     int32_t *parent;     // [n][N] union-find forest, root = smallest flat index of the component
@@ -75,6 +96,7 @@ struct CcWork {
     int32_t *newid;      // [n][N] final id per surviving root
     int32_t *blocksum;   // [n][nblk]
     int32_t *nlabels;    // [n] largest id per image
+    int32_t *clear = nullptr;   // [n] words zeroed on the way (or null)
 };
 size_t cc_blocks_per_image(int H, int W);
 void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_size_exclusive, int64_t *labels64,

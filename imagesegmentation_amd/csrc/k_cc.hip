@@ -268,7 +268,8 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_blocksum_kernel(const int32_t *__
 }
 
 // one block per image: exclusive scan of the per-block survivor counts
-__global__ __launch_bounds__(1024) void cc_scan_kernel(int32_t *__restrict__ blocksum, int32_t *__restrict__ nlabels, int nblk)
+__global__ __launch_bounds__(1024) void cc_scan_kernel(int32_t *__restrict__ blocksum, int32_t *__restrict__ nlabels,
+                                                       int32_t *__restrict__ clear, int nblk)
 {
     __shared__ int part[1024];
     int32_t *bs = blocksum + (size_t)blockIdx.x * nblk;
@@ -292,7 +293,10 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(int32_t *__restrict__ blo
             bs[b0 + i] = run;
             run += v;
         }
-    if (threadIdx.x == 1023) nlabels[blockIdx.x] = part[1023];
+    if (threadIdx.x == 1023) {
+        nlabels[blockIdx.x] = part[1023];
+        if (clear) clear[blockIdx.x] = 0;
+    }
 }
 
 __global__ __launch_bounds__(CC_BLOCK) void cc_rank_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
@@ -463,14 +467,14 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
         const dim3 block4(CC_VT);
         hipLaunchKernelGGL(cc_sum_sizes4_kernel, grid, block4, 0, st, w.parent, w.count, w.newid, N);
         hipLaunchKernelGGL(cc_blocksum4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
-        hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
+        hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
         hipLaunchKernelGGL(cc_rank4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
         hipLaunchKernelGGL(cc_relabel4_kernel, grid, block4, 0, st, w.parent, w.newid, labels64, labels32, N);
         return;
     }
     hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
-    hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, nblk);
+    hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
     hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
     hipLaunchKernelGGL(cc_relabel_kernel, grid, block, 0, st, w.parent, w.newid, labels64, labels32, N);
 }

@@ -356,7 +356,8 @@ __device__ __forceinline__ float curvature_total(Depth depth, float dc, float df
 __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restrict__ D, const float *__restrict__ ax,
                                                             const float *__restrict__ ay, float threshold,
                                                             uint8_t *__restrict__ mask, float *__restrict__ scores,
-                                                            int32_t *__restrict__ todo, int todo_cap, int H, int W)
+                                                            int32_t *__restrict__ todo, int32_t *__restrict__ todo_list, int todo_cap,
+                                                            int H, int W)
 {
     constexpr int R = 4;
     __shared__ float tile[TH + 2 * R][TW + 2 * R + 1];
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
         return;
     }
     // A wave with a single undecided lane would spend ten times the approximate evaluation on it, and about
-    // one wave in twenty has one: undecided pixels go to a per-frame list (todo = counts[frames], then lists[frames][todo_cap] of
+    // one wave in twenty has one: undecided pixels go to a per-frame list (todo[frame] entries of todo_list[frame][todo_cap],
     // pixel indices) that curvature_exact_kernel works through with full waves; only when the list is full (or
     // absent) the exact evaluation runs here.
     auto at = [&](int oy, int ox) { return tile[ty + R + oy][tx + R + ox]; };
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
         if (!decided && todo_cap > 0) {
             const int slot = atomicAdd(todo + blockIdx.z, 1);
             if (slot < todo_cap) {
-                todo[gridDim.z + (size_t)blockIdx.z * todo_cap + slot] = r * W + c;
+                todo_list[(size_t)blockIdx.z * todo_cap + slot] = r * W + c;
                 return;
             }
         }
@@ -426,9 +427,9 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
 __global__ __launch_bounds__(256) void curvature_exact_kernel(const float *__restrict__ D, const float *__restrict__ ax,
                                                               const float *__restrict__ ay, float threshold,
                                                               uint8_t *__restrict__ mask, const int32_t *__restrict__ todo,
-                                                              int todo_cap, int H, int W)
+                                                              const int32_t *__restrict__ todo_list, int todo_cap, int H, int W)
 {
-    const int32_t *list = todo + gridDim.y + (size_t)blockIdx.y * todo_cap;
+    const int32_t *list = todo_list + (size_t)blockIdx.y * todo_cap;
     const int count = min(todo[blockIdx.y], todo_cap);
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
@@ -454,9 +455,11 @@ constexpr int MTH = 32;   // tile height of the majority / edge kernel: 256 lane
 __global__ __launch_bounds__(NT) void majority_edges_kernel(const uint8_t *__restrict__ curv, const float *__restrict__ D,
                                                             const float *__restrict__ ax, const float *__restrict__ ay,
                                                             float alpha, uint8_t *__restrict__ mask,
-                                                            int32_t *__restrict__ edges, int H, int W)
+                                                            int32_t *__restrict__ edges, int32_t *__restrict__ clear, int H, int W)
 {
     constexpr int R = 3;
+    // the curvature pass's list counter of this frame has been consumed by now: zero it for the next call
+    if (clear && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clear[blockIdx.z] = 0;
     __shared__ float tm[MTH + 2 * R][TW + 2 * R + 1];
     __shared__ float td[MTH + 2][TW + 2 + 1];
     __shared__ int m5[MTH + 2][TW + 2 + 1];
@@ -539,23 +542,28 @@ void launch_angle_filter(const float *raw_angles, const float *D, float *angles,
     hipLaunchKernelGGL(angle_filter_kernel, dim3((W + TW - 1) / TW, (H + ATH - 1) / ATH, n), dim3(NT), 0, st, raw_angles, D, angles,
                        reinterpret_cast<float2 *>(feat), feat_scale, H, W);
 }
-void launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
-                           float *scores, int32_t *todo, int todo_cap, int n, int H, int W, hipStream_t st)
+bool launch_curvature_mask(const float *D, const float *ax, const float *ay, float threshold, uint8_t *mask,
+                           float *scores, int32_t *todo, int todo_cap, int todo_frames, bool todo_zeroed, int n, int H, int W, hipStream_t st)
 {
-    if (scores || !todo || todo_cap < 256) {
-        hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, nullptr, 0, H, W);
-        return;
+    if (scores || !todo || todo_cap < 256 || n > todo_frames) {
+        hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, nullptr, nullptr,
+                           0, H, W);
+        return false;
     }
-    (void)hipMemsetAsync(todo, 0, (size_t)n * sizeof(int32_t), st);
-    hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, todo, todo_cap, H, W);
-    hipLaunchKernelGGL(curvature_exact_kernel, dim3((todo_cap + 255) / 256, n), dim3(256), 0, st, D, ax, ay, threshold, mask, todo,
+    int32_t *lists = todo + todo_frames;                // counters of all frames first, at a fixed place, then the lists
+    if (!todo_zeroed) (void)hipMemsetAsync(todo, 0, (size_t)todo_frames * sizeof(int32_t), st);
+    hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, todo, lists, todo_cap,
+                       H, W);
+    hipLaunchKernelGGL(curvature_exact_kernel, dim3((todo_cap + 255) / 256, n), dim3(256), 0, st, D, ax, ay, threshold, mask, todo, lists,
                        todo_cap, H, W);
+    return true;
 }
-size_t curvature_todo_ints(int n, int todo_cap) { return (size_t)n * (1 + (size_t)todo_cap); }
+size_t curvature_todo_ints(int frames, int todo_cap) { return (size_t)frames * (1 + (size_t)todo_cap); }
 void launch_majority_edges(const uint8_t *curv, const float *D, const float *ax, const float *ay, float alpha,
-                           uint8_t *mask, int32_t *edges, int n, int H, int W, hipStream_t st)
+                           uint8_t *mask, int32_t *edges, int32_t *clear, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(majority_edges_kernel, dim3((W + TW - 1) / TW, (H + MTH - 1) / MTH, n), dim3(NT), 0, st, curv, D, ax, ay, alpha, mask, edges, H, W);
+    hipLaunchKernelGGL(majority_edges_kernel, dim3((W + TW - 1) / TW, (H + MTH - 1) / MTH, n), dim3(NT), 0, st, curv, D, ax, ay, alpha, mask, edges,
+                       clear, H, W);
 }
 
 }  // namespace fs
