@@ -8,6 +8,7 @@ import ctypes
 import json
 import os
 import struct
+import threading
 
 import numpy as np
 
@@ -94,23 +95,66 @@ def lr_parameters():
     return np.asarray(list(doc["coef"]) + [doc["intercept"] + 4, 0.01, 15000], np.float32)
 
 
+# Page-locking memory costs about a millisecond per few megabytes, more than the stage takes for a frame, so blocks
+# that their arrays have let go are kept for the next request of a similar size (up to _POOL_LIMIT bytes in all).
+_POOL = {}                  # block size -> addresses of free blocks
+_POOL_BYTES = 0
+_POOL_LIMIT = 1 << 30
+_POOL_LOCK = threading.Lock()
+
+
+def _block_size(nbytes):
+    """Sizes come in eight steps per power of two, so that a request finds the block an earlier, slightly different one left."""
+    n = max(int(nbytes), 4096)
+    step = 1 << max(n.bit_length() - 4, 12)
+    return (n + step - 1) // step * step
+
+
 class _PinnedBlock:
     """Page-locked host allocation that lives as long as an array built on it."""
 
     def __init__(self, nbytes):
+        global _POOL_BYTES
         self._lib = load()
-        self.ptr = self._lib.fs_host_alloc(max(int(nbytes), 1))
+        self.size = _block_size(nbytes)
+        self.ptr = None
+        with _POOL_LOCK:
+            free = _POOL.get(self.size)
+            if free:
+                self.ptr = free.pop()
+                _POOL_BYTES -= self.size
         if not self.ptr:
-            raise MemoryError(f"fs_host_alloc({nbytes}) failed")
+            self.ptr = self._lib.fs_host_alloc(self.size)
+        if not self.ptr:
+            raise MemoryError(f"fs_host_alloc({self.size}) failed")
         self.nbytes = int(nbytes)
 
     def __del__(self):
+        global _POOL_BYTES
         try:
-            if getattr(self, "ptr", None):
-                self._lib.fs_host_free(self.ptr)
-                self.ptr = None
+            ptr, self.ptr = getattr(self, "ptr", None), None
+            if not ptr:
+                return
+            with _POOL_LOCK:
+                if _POOL_BYTES + self.size <= _POOL_LIMIT:
+                    _POOL.setdefault(self.size, []).append(ptr)
+                    _POOL_BYTES += self.size
+                    return
+            self._lib.fs_host_free(ptr)
         except Exception:      # interpreter shutdown: the library may already be gone
             pass
+
+
+def release_pinned_pool():
+    """Return the kept page-locked blocks to the system."""
+    global _POOL_BYTES
+    with _POOL_LOCK:
+        blocks = [p for free in _POOL.values() for p in free]
+        _POOL.clear()
+        _POOL_BYTES = 0
+    lib = load()
+    for p in blocks:
+        lib.fs_host_free(p)
 
 
 def pinned_empty(shape, dtype):

@@ -17,16 +17,23 @@ int ctx_fail(fs_ctx *ctx, const std::string &message);      // records the messa
 // work space of fs_connected_components_noalloc (fs_noalloc.hip): address of this GPU's copy, looked up once
 hipError_t noalloc_scratch_init(int device, int32_t **out);
 
-// Grow-only device buffer owned by a context.
+// Grow-only device buffer owned by a context.  A buffer that has to grow takes a quarter more than asked (requests
+// that creep up, e.g. with the number of surfaces of a frame, then cost a few reallocations instead of one each:
+// hipFree + hipMalloc is tens of milliseconds); the first allocation is exact.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
+        size_t want = bytes;
+        if (p) {
+            want = bytes + bytes / 4;
+            hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && want != bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
+        if (e == hipSuccess) cap = want;
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }

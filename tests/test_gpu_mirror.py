@@ -250,3 +250,26 @@ def test_position_dependent_weights_with_a_larger_window(oracle):
     assert _ties_only(got["surfaces"], ref["surfaces"], ref["q_final"])
     print("label disagreement:", float((got["surfaces"] != ref["surfaces"]).mean()))
     assert (got["surfaces"] != ref["surfaces"]).mean() <= 0.003
+
+
+def test_pinned_blocks_are_reused():
+    """Page-locked blocks whose arrays are gone serve the next request of a similar size (locking pages costs more than
+    the stage takes for a frame); release_pinned_pool hands them back."""
+    from imagesegmentation_amd import _lib
+    _lib.release_pinned_pool()
+    a = _lib.pinned_empty((480, 640, 3), np.float64)
+    a[...] = 1.0
+    addr = a.ctypes.data
+    del a
+    b = _lib.pinned_empty((480, 640, 3), np.float64)
+    assert b.ctypes.data == addr
+    c = _lib.pinned_empty((480, 640, 3), np.float64)           # b is still alive: a block of its own
+    assert c.ctypes.data != addr
+    c[...] = 2.0
+    b[...] = 3.0
+    assert float(c[0, 0, 0]) == 2.0
+    del b, c
+    assert _lib._POOL_BYTES == 2 * _lib._block_size(480 * 640 * 3 * 8)
+    _lib.release_pinned_pool()
+    assert _lib._POOL_BYTES == 0 and not _lib._POOL
+    assert [_lib._block_size(n) >= n for n in (1, 4096, 4097, 10 ** 6, 10 ** 9)] == [True] * 5

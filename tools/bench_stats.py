@@ -88,13 +88,17 @@ def main(args):
     from imagesegmentation_amd import process_surfaces as ps
     model = fs.find_surface_model("Gauss", args.kernel_size)
     datas = [model((depth[i], rgb[i], None)) for i in range(min(n, 8))]
-    ps.extract_information_from_surface_data_and_preprocess_surfaces(dict(datas[0]), None)
+    for dct in datas:               # buffers (device work space, page-locked blocks) grow to the frames' sizes once
+        ps.extract_information_from_surface_data_and_preprocess_surfaces(dict(dct), None)
     t1 = time.perf_counter()
     for dct in datas:
-        ps.extract_information_from_surface_data_and_preprocess_surfaces(dct, None)
+        # one image at a time, its results dropped before the next one (the reference's loops, e.g. main.py:25-26): the
+        # page-locked output blocks of a frame then serve the next frame
+        ps.extract_information_from_surface_data_and_preprocess_surfaces(dict(dct), None)
     out["value_host_mirror"] = {"value": len(datas) / (time.perf_counter() - t1), "unit": "frames/s",
                                 "note": "process_surfaces.extract_information_from_surface_data_and_preprocess_surfaces per frame: numpy "
-                                        "arrays in, numpy arrays out (PCIe both ways, S x S tails in numpy)"}
+                                        "arrays in, numpy arrays out (PCIe both ways, S x S tails in numpy), each frame's results "
+                                        "released before the next call"}
     if want_cpu:
         from imagesegmentation_amd.utils import rgb_to_Lab
         os.environ["OMP_NUM_THREADS"] = "1"
