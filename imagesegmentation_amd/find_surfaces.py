@@ -314,10 +314,17 @@ def find_surfaces_for_indices(image_indices, mode="Gauss", kernel_size=standard_
     results = []
     with ThreadPoolExecutor(max_workers=io_workers) as pool:
         pending_saves = []
-        for lo in range(0, len(image_indices), frames_per_call):
+        starts = list(range(0, len(image_indices), frames_per_call))
+        decoding = {}                                       # chunk start -> futures; the next chunk decodes during this one's GPU call
+        for lo in starts[:1]:
+            decoding[lo] = [pool.submit(load_image, i) for i in image_indices[lo:lo + frames_per_call]]
+        for lo in starts:
             chunk = image_indices[lo:lo + frames_per_call]
             t0 = time.perf_counter()
-            images = list(pool.map(load_image, chunk))
+            nxt = lo + frames_per_call
+            if nxt < len(image_indices):
+                decoding[nxt] = [pool.submit(load_image, i) for i in image_indices[nxt:nxt + frames_per_call]]
+            images = [f.result() for f in decoding.pop(lo)]
             shapes = {im[0].shape for im in images}
             if len(shapes) != 1:
                 raise ValueError(f"images of one call must share a size, got {sorted(shapes)}")

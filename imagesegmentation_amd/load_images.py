@@ -7,6 +7,8 @@ first, then ``$FS_DATA_ROOT``, then the OSD copy shipped with this repository.
 """
 import os
 import re
+import struct
+import zlib
 
 import numpy as np
 
@@ -32,13 +34,70 @@ def sorted_alphanumeric(data):
     return sorted(data, key=key)
 
 
+def _png_plain(path):
+    """Decodes the plain kind of PNG the data set consists of (grey or RGB, 8 or 16 bits, not interlaced, rows filtered with
+    None / Sub / Up) with zlib and numpy, which release the interpreter lock for the bulk of the work, so a pool of loader
+    threads scales (PIL holds the lock for most of a decode).  Returns None for any other file: the caller then uses PIL."""
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:8] != b"\x89PNG\r\n\x1a\n":
+        return None
+    pos, header, parts = 8, None, []
+    while pos + 12 <= len(b):
+        (length,), kind = struct.unpack(">I", b[pos:pos + 4]), b[pos + 4:pos + 8]
+        if kind == b"IHDR":
+            header = struct.unpack(">IIBBBBB", b[pos + 8:pos + 21])
+        elif kind == b"IDAT":
+            parts.append(b[pos + 8:pos + 8 + length])
+        elif kind == b"IEND":
+            break
+        pos += 12 + length
+    if header is None:
+        return None
+    w, h, bits, colour, compression, filtering, interlace = header
+    if bits not in (8, 16) or colour not in (0, 2) or compression or filtering or interlace:
+        return None
+    channels = 3 if colour == 2 else 1
+    bpp = channels * bits // 8                      # bytes per pixel: the distance the Sub filter looks back
+    raw = np.frombuffer(zlib.decompress(b"".join(parts)), np.uint8)
+    if raw.size != h * (1 + w * bpp):
+        return None
+    raw = raw.reshape(h, 1 + w * bpp)
+    filters = raw[:, 0]
+    if filters.max(initial=0) > 2:
+        return None                                 # Average / Paeth rows: a per-byte recurrence, left to PIL
+    x = raw[:, 1:].reshape(h, w, bpp)
+    sub = filters == 1
+    if sub.all():
+        x = np.cumsum(x, axis=1, dtype=np.uint8)    # Sub: byte + the same byte of the pixel to the left, modulo 256
+    else:
+        x = x.copy()
+        if sub.any():
+            x[sub] = np.cumsum(x[sub], axis=1, dtype=np.uint8)
+        for r in np.nonzero(filters == 2)[0]:       # Up: byte + the byte above (the finished row), in row order
+            if r > 0:
+                x[r] += x[r - 1]
+    if bits == 16:
+        x = x.reshape(h, w, channels, 2)
+        x = (x[..., 0].astype(np.uint16) << 8) | x[..., 1]
+    return x.reshape(h, w) if channels == 1 else x.reshape(h, w, channels)
+
+
+def read_png(path):
+    """numpy array of a PNG file: what np.asarray(PIL.Image.open(path)) gives."""
+    img = _png_plain(path)
+    if img is None:
+        from PIL import Image
+        img = np.asarray(Image.open(path))
+    return img
+
+
 def load_image(index):
     """-> (depth uint16 [H,W], rgb uint8 [H,W,3], annotation uint8 [H,W]); `index`
     selects from the naturally sorted listing of disparity/ (load_images.py:13-20)."""
-    from PIL import Image
     root = _data_root()
     name = sorted_alphanumeric(os.listdir(os.path.join(root, "disparity")))[index]
-    return tuple(np.asarray(Image.open(os.path.join(root, sub, name))) for sub in ("disparity", "RGB", "annotation"))
+    return tuple(read_png(os.path.join(root, sub, name)) for sub in ("disparity", "RGB", "annotation"))
 
 
 def save_surface_information(index, data):

@@ -165,6 +165,9 @@ def test_batch_and_shard_invariance():
             assert np.array_equal(part["num_surfaces"], whole["num_surfaces"][mine])
         one = ctx.find_surfaces_batch(d[4], c[4])
         assert np.array_equal(one["surfaces"], whole["surfaces"][4])
+        again = ctx.find_surfaces_batch(d, c)          # a larger batch after smaller ones: per-frame counters kept between calls
+        for k in ("surfaces", "patches", "depth_edges"):
+            assert np.array_equal(again[k], whole[k]), k
     # labels are a subset of {0} + patch labels, and patch pixels with valid depth keep... nothing is
     # guaranteed about keeping, but every label in the output must exist as a patch
     for i in range(len(idx)):

@@ -216,3 +216,64 @@ def test_bench_executed_work_model():
     assert flops == want
     assert q_bytes == 512 * 4 * 2 * (4 + 9 + 17) + 32 * 64 * 28.0
     assert info["tiles_skipped_frac"] == 0.25 and info["channels_per_tile_max"] == 17
+
+
+def _write_png(path, img, filters):
+    """A PNG with the given filter type per row (0 None, 1 Sub, 2 Up), written by hand, its stream split over two IDAT chunks."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    channels = 1 if img.ndim == 2 else img.shape[2]
+    bits = 8 * img.dtype.itemsize
+    raw = img.astype(">u2").view(np.uint8).reshape(h, -1) if bits == 16 else img.reshape(h, -1)
+    bpp = channels * bits // 8
+    rows = []
+    for r in range(h):
+        cur = raw[r].astype(np.int32)
+        if filters[r] == 1:
+            out = cur - np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        elif filters[r] == 2:
+            out = cur - (raw[r - 1].astype(np.int32) if r else 0)
+        else:
+            out = cur
+        rows.append(bytes([filters[r]]) + (out % 256).astype(np.uint8).tobytes())
+    stream = zlib.compress(b"".join(rows))
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bits, 2 if channels == 3 else 0, 0, 0, 0)) +
+                chunk(b"IDAT", stream[:len(stream) // 2]) + chunk(b"IDAT", stream[len(stream) // 2:]) + chunk(b"IEND", b""))
+
+
+def test_png_reader_equals_pil(tmp_path):
+    """load_image's own PNG decoder (zlib + numpy, for loader threads that scale) gives PIL's arrays: on every file of the
+    data set, on hand-written files with None / Sub / Up rows, and through the PIL fall-back on files it does not take."""
+    from PIL import Image
+    from imagesegmentation_amd import load_images as L
+    root = os.path.join(ROOT, "data", "osd")
+    if os.path.isdir(os.path.join(root, "disparity")):
+        for sub in ("disparity", "RGB", "annotation"):
+            for name in sorted(os.listdir(os.path.join(root, sub))):
+                path = os.path.join(root, sub, name)
+                mine, ref = L._png_plain(path), np.asarray(Image.open(path))
+                assert mine is not None and mine.dtype == ref.dtype and np.array_equal(mine, ref), path
+    rng = np.random.default_rng(5)
+    for k, (shape, dt) in enumerate((((37, 53), np.uint8), ((37, 53), np.uint16), ((20, 31, 3), np.uint8))):
+        img = rng.integers(0, np.iinfo(dt).max, shape, endpoint=True).astype(dt)
+        path = str(tmp_path / f"hand{k}.png")
+        _write_png(path, img, [int(v) for v in rng.integers(0, 3, shape[0])])
+        assert np.array_equal(np.asarray(Image.open(path)), img), "the hand-written file is not what was meant"
+        mine = L._png_plain(path)
+        assert mine is not None and mine.dtype == img.dtype and np.array_equal(mine, img), (shape, dt)
+    # PIL's encoder picks Paeth / Average rows for a noisy image, and palette images are another colour type: not taken,
+    # read through PIL all the same
+    noisy = rng.integers(0, 255, (40, 40, 3), endpoint=True).astype(np.uint8)
+    smooth = (np.add.outer(np.arange(40), np.arange(40))[..., None] * np.array([1, 2, 3])).astype(np.uint8)
+    for k, arr in enumerate((noisy, smooth)):
+        path = str(tmp_path / f"pil{k}.png")
+        Image.fromarray(arr).save(path)
+        assert np.array_equal(L.read_png(path), arr)
+    Image.fromarray(noisy[..., 0]).convert("P").save(str(tmp_path / "pal.png"))
+    assert L._png_plain(str(tmp_path / "pal.png")) is None
+    assert np.array_equal(L.read_png(str(tmp_path / "pal.png")), np.asarray(Image.open(str(tmp_path / "pal.png"))))
