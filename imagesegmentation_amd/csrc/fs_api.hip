@@ -272,7 +272,10 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
         // label counts and per-frame maxima
         if (const int th = crf_fused_tile_height(ctx->r)) {
             ScopedTimer t(ctx, G_INIT);
-            launch_crf_tile_active(d_patches32, n, H, W, 32, th, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
+            // the tile queues of the updates are cleared on the way: one memset less in front of the CRF
+            launch_crf_tile_active(d_patches32, n, H, W, 32, th, ctx->r * 3, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream,
+                                   ctx->crf_queue.as<unsigned>(), (int)(kCrfQueueSlots * kCrfQueueBytes / sizeof(unsigned)));
+            ctx->queue_clean = true;
         }
         FS_HIP(hipMemcpyAsync(ctx->counts_host.p, ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(hipStreamSynchronize(ctx->stream));
@@ -820,22 +823,14 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     const bool fused_crf = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;     // as run_crf_batch decides
     {
         ScopedTimer t(ctx, G_STENCIL);
-        launch_smooth_depth_u16(d_depth, ctx->smoothed.as<float>(), n, H, W, ctx->stream);                 // find_surfaces.py:505
+        // (the colour half of the fused CRF update's feature records is written on the way: it needs the same depth)
+        launch_smooth_depth_u16(d_depth, ctx->smoothed.as<float>(), n, H, W, ctx->stream, fused_crf ? d_rgb : nullptr,
+                                fused_crf ? ctx->featA.p : nullptr, crf_colour_feature_scale(ctx->params));   // find_surfaces.py:505
         launch_normals(ctx->smoothed.as<float>(), ctx->tanx.as<float>(), ctx->tany.as<float>(), points, vectors,
                        ctx->raw.as<float>(), n, H, W, ctx->stream);                                            // :507
         // the fused CRF update wants the angles once more, scaled, in its feature records: the filter writes both
         launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, fused_crf ? ctx->featB.p : nullptr,
                             crf_angle_feature_scale(ctx->params), n, H, W, ctx->stream);
-    }
-    if (fused_crf) {
-        // what the CRF needs and the label counts do not decide goes in front of the read-back of those counts: the
-        // other half of the feature records, and clean tile queues
-        {
-            ScopedTimer t(ctx, G_SIM);
-            launch_crf_pack_features(d_depth, d_rgb, nullptr, ctx->featA.p, ctx->featB.p, (size_t)n * ctx->N(), ctx->params, ctx->stream);
-        }
-        FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
-        ctx->queue_clean = true;
     }
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
                     ctx->curv.as<uint8_t>(), true))                                                            // :513

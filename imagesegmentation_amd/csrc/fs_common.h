@@ -77,7 +77,10 @@ constexpr int kMaxRadius = 15;    // largest CRF window radius (kernel_size)
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----
 // stencils (k_stencils.hip)
-void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, int W, hipStream_t st);
+// rgb, featA (both or neither): also writes the (depth, r, g, b) half of the fused CRF update's feature records,
+// colours times colour_scale = crf_colour_feature_scale(P) (what launch_crf_pack_features writes)
+void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, int W, hipStream_t st, const uint8_t *rgb = nullptr,
+                             void *featA = nullptr, float colour_scale = 0.0f);
 void launch_smooth_depth_f32(const float *depth, float *out, int n, int H, int W, hipStream_t st);
 void launch_normals(const float *D, const float *tanx, const float *tany, float *points, float *normals,
                     float *raw_angles, int n, int H, int W, hipStream_t st);
@@ -198,8 +201,9 @@ void launch_crf_init(const CrfFrameDesc *descs, int nframes, int H, int W, hipSt
 void launch_rows_to_planes(const float *rows, float *planes, size_t P, int S, hipStream_t st);
 void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hipStream_t st);
 // patch labels present within `grow` pixels of every tile_w x tile_h tile, for n frames; max_active[n] must be zeroed
+// clear (may be null): clear_words words zeroed on the way (the tile queues of the updates that follow)
 void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
-                            int32_t *max_active, hipStream_t st);
+                            int32_t *max_active, hipStream_t st, unsigned *clear = nullptr, int clear_words = 0);
 // number of listed labels of `total` consecutive tile records -> out[total] (device pointers)
 void launch_crf_tile_counts(const int32_t *recs, int32_t *out, int total, hipStream_t st);
 // mode bits for launch_crf_iter
@@ -219,6 +223,7 @@ void crf_fused_tile_grid(int H, int W, int r, int *tiles_x, int *tiles_y);
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
                               size_t total, const CrfParams &P, hipStream_t st);
 float crf_angle_feature_scale(const CrfParams &P);
+float crf_colour_feature_scale(const CrfParams &P);
 // CRF_FIRST: Q is synthesised from descs[].patches instead of read from Qin.  Q planes are compact: only the
 // planes of a tile's listed labels and of its representative are written (see k_crf.hip).
 // tile_queue: kCrfQueueBytes of zeroed device memory that no other launch in flight uses (the caller keeps

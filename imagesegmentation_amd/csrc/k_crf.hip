@@ -277,9 +277,11 @@ constexpr int ITW = 64, ITH = 16;             // tile of the update kernel
 
 __global__ __launch_bounds__(256) void crf_tile_active_kernel(const int32_t *__restrict__ patches, int H, int W, int tw, int th,
                                                               int grow, int tiles_x, int tiles_y, int total_tiles,
-                                                              int32_t *__restrict__ recs, int32_t *__restrict__ max_active)
+                                                              int32_t *__restrict__ recs, int32_t *__restrict__ max_active,
+                                                              unsigned *__restrict__ clear, int clear_words)
 {
     __shared__ unsigned mask[MASK_WORDS];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < clear_words; i += gridDim.x * 256) clear[i] = 0u;
     // consecutive workgroups go to different XCDs (one L2 each): give every XCD a contiguous run of tiles so
     // that the overlapping surroundings of neighbouring tiles are served by one L2
     const int per_xcd = gridDim.x >> 3;
@@ -682,12 +684,12 @@ void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hi
 }
 
 void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
-                            int32_t *max_active, hipStream_t st)
+                            int32_t *max_active, hipStream_t st, unsigned *clear, int clear_words)
 {
     const int tx = (W + tile_w - 1) / tile_w, ty = (H + tile_h - 1) / tile_h;
     const int total = tx * ty * n;
     hipLaunchKernelGGL(crf_tile_active_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, st, patches, H, W, tile_w, tile_h, grow, tx, ty,
-                       total, recs, max_active);
+                       total, recs, max_active, clear, clear ? clear_words : 0);
 }
 
 // word 0 (number of listed labels) of every tile record, gathered into a dense array
@@ -715,11 +717,12 @@ static double fused_c2(const CrfParams &P) { return P.t23 / 2500.0 * 1.442695040
 static double fused_c3(const CrfParams &P) { return 4.0 * P.t33 * 1.4426950408889634; }
 
 float crf_angle_feature_scale(const CrfParams &P) { return P.mode == 0 ? (float)std::sqrt(fused_c3(P)) : 1.0f; }
+float crf_colour_feature_scale(const CrfParams &P) { return P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f; }
 
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
                               size_t total, const CrfParams &P, hipStream_t st)
 {
-    const float cs = P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f, as = crf_angle_feature_scale(P);
+    const float cs = crf_colour_feature_scale(P), as = crf_angle_feature_scale(P);
     hipLaunchKernelGGL(crf_pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, depth, rgb, angles,
                        reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total, cs, as);
 }

@@ -179,13 +179,18 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         return 0xffffffffu;
     };
     unsigned next_ticket = 0;
+    // The next tile is requested while the current one is worked on, which hides the counter's latency.  With few
+    // tiles per block that early claim would tie the last tiles of a run to blocks that are busy for another tile's
+    // length while idle blocks find the queues empty (one frame: 600 tiles, 512 blocks, a second round for 62 tiles):
+    // a small launch claims its next tile only when the window walk is over, in front of the epilogue.
+    const bool claim_early = tiles_total > 2u * gridDim.x;
     if (threadIdx.x == 0) s_ticket = next_tile();
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();
   for (;;) {
     const unsigned tile_id = s_ticket;
     if (tile_id == 0xffffffffu) break;
-    if (threadIdx.x == 0) next_ticket = next_tile();
+    if (claim_early && threadIdx.x == 0) next_ticket = next_tile();
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         }
     }
 
+    if (!claim_early && threadIdx.x == 0) next_ticket = next_tile();
     if (FS_SKIPFIN) {                              // timing experiments: keep the messages alive without the epilogue
         f2 t = f2{0.0f, 0.0f};
 #pragma unroll

@@ -40,8 +40,11 @@ __device__ __forceinline__ void load_tile(float (*tile)[TW + 2 * R + 1], const T
 // ---------------------------------------------------------------------------
 constexpr int STH = 32;   // tile height of the 16-bit smoothing: 256 lanes x 4 rows (the halo is 1.4x the tile instead of 2.1x)
 
+// rgb / feat (16-bit depths only, may be null): the kernel also writes the (depth, r, g, b) half of the CRF's feature
+// records, feat[p] = (depth, cscale r, cscale g, cscale b), for the pixels it smooths (launch_crf_pack_features' values).
 template <typename T>
-__global__ __launch_bounds__(NT) void smooth_depth_kernel(const T *__restrict__ depth, float *__restrict__ out, int H, int W)
+__global__ __launch_bounds__(NT) void smooth_depth_kernel(const T *__restrict__ depth, float *__restrict__ out, int H, int W,
+                                                          const uint8_t *__restrict__ rgb, float4 *__restrict__ feat, float cscale)
 {
     constexpr int R = 3;
     constexpr int LTH = sizeof(T) == 2 ? STH : TH;          // rows of the tile
@@ -83,7 +86,9 @@ __global__ __launch_bounds__(NT) void smooth_depth_kernel(const T *__restrict__ 
                 val = val + hsum[ty + wy][tx];
             }
             const float c = tile[ty + R][tx + R];
-            out[fo + (size_t)y * W + x] = div_no_nan(val, sums) * (c < 0.001f ? 0.0f : 1.0f);
+            const size_t q = fo + (size_t)y * W + x;
+            out[q] = div_no_nan(val, sums) * (c < 0.001f ? 0.0f : 1.0f);
+            if (feat) feat[q] = make_float4(c, cscale * (float)rgb[3 * q], cscale * (float)rgb[3 * q + 1], cscale * (float)rgb[3 * q + 2]);
         }
     } else {
         const int ty = threadIdx.x / TW, y = y0 + ty;
@@ -523,13 +528,15 @@ inline dim3 tile_grid(int n, int H, int W) { return dim3((W + TW - 1) / TW, (H +
 
 }  // namespace
 
-void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, int W, hipStream_t st)
+void launch_smooth_depth_u16(const uint16_t *depth, float *out, int n, int H, int W, hipStream_t st, const uint8_t *rgb, void *featA,
+                             float colour_scale)
 {
-    hipLaunchKernelGGL(smooth_depth_kernel<uint16_t>, dim3((W + TW - 1) / TW, (H + STH - 1) / STH, n), dim3(NT), 0, st, depth, out, H, W);
+    hipLaunchKernelGGL(smooth_depth_kernel<uint16_t>, dim3((W + TW - 1) / TW, (H + STH - 1) / STH, n), dim3(NT), 0, st, depth, out, H, W,
+                       rgb, rgb ? reinterpret_cast<float4 *>(featA) : nullptr, colour_scale);
 }
 void launch_smooth_depth_f32(const float *depth, float *out, int n, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(smooth_depth_kernel<float>, tile_grid(n, H, W), dim3(NT), 0, st, depth, out, H, W);
+    hipLaunchKernelGGL(smooth_depth_kernel<float>, tile_grid(n, H, W), dim3(NT), 0, st, depth, out, H, W, nullptr, nullptr, 0.0f);
 }
 void launch_normals(const float *D, const float *tanx, const float *tany, float *points, float *normals,
                     float *raw_angles, int n, int H, int W, hipStream_t st)
