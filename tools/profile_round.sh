@@ -16,6 +16,7 @@ trace() {   # name, bench args...
 }
 trace osd --steps 5 --warmup 2 --no-host-leg
 trace osd_hostbuf --host-buffers --steps 5 --warmup 2
+trace osd_one_frame --frames 1 --steps 200 --warmup 5 --no-host-leg --no-kernel-timing
 trace m1280_s32_r7 --workload mosaic1280 --labels 32 --kernel-size 7 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s32_r10 --workload mosaic1280 --labels 32 --kernel-size 10 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s64_r15 --workload mosaic1280 --labels 64 --kernel-size 15 --steps 3 --warmup 1 --no-host-leg
