@@ -220,17 +220,29 @@ class Context:
     def __exit__(self, *exc):
         self.close()
 
+    def _same_params(self, p, mode):
+        """True if the context already holds exactly these parameters (setting them drains the stream and uploads the
+        weight tables: callers that pass their parameters with every frame should not pay that per frame)."""
+        have = getattr(self, "params", None)
+        return getattr(self, "_params_mode", None) == mode and have is not None and have.shape == p.shape and have.tobytes() == p.tobytes()
+
     def set_gauss_params(self, params):
         p = _arr(np.asarray(params, np.float32).reshape(-1), np.float32, (13,))
-        self.params = p
+        if self._same_params(p, "gauss"):
+            return
         self._check(self._lib.fs_set_gauss_params(self._h, _ptr(p)))
+        self.params, self._params_mode = p.copy(), "gauss"
 
     def set_lr_params(self, params):
         p = _arr(np.asarray(params, np.float32).reshape(-1), np.float32, (7,))
-        self.params = p
+        if self._same_params(p, "lr"):
+            return
         self._check(self._lib.fs_set_lr_params(self._h, _ptr(p)))
+        self.params, self._params_mode = p.copy(), "lr"
 
     def set_kernel_size(self, r):
+        if int(r) == getattr(self, "kernel_size", None):
+            return
         self._check(self._lib.fs_set_kernel_size(self._h, int(r)))
         self.kernel_size = int(r)
 
