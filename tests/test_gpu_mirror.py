@@ -218,6 +218,38 @@ def test_degenerate_frames(oracle):
             ctx.find_surfaces_batch(d[:2], c[:2])     # batch larger than max_batch
 
 
+def test_label_limits_fail_loudly():
+    """More labels than the library carries (512 channels per frame, 128 around one tile) are an error with a message,
+    never a wrong result; the context stays usable afterwards."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = 96, 128
+    d, c = make_batch([7], H, W)
+    ang = np.zeros((H, W, 2), np.float32)
+    with Context(H, W, max_batch=1) as ctx:
+        labels = np.zeros((H, W), np.int64)
+        labels[5, 5] = 600
+        with pytest.raises(RuntimeError, match="outside"):
+            ctx.apply_crf(labels, d[0], c[0], ang)
+        # 2x2 cells, 500 labels in turn: all of them near any tile
+        labels = 1 + (np.arange(H // 2)[:, None] * (W // 2) + np.arange(W // 2)[None, :]) % 500
+        labels = np.repeat(np.repeat(labels, 2, 0), 2, 1).astype(np.int64)
+        with pytest.raises(RuntimeError, match="label channels; at most 128"):
+            ctx.apply_crf(labels, d[0], c[0], ang)
+        ok = ctx.find_surfaces_batch(d, c)                 # the context still works
+        assert ok["surfaces"].shape == (1, H, W)
+    # a frame that the front end cuts into more than 510 patches: flat 24x24 cells, each at a depth of its own
+    H, W = 960, 1280
+    cell = (np.arange(-(-H // 24))[:, None] * 7 + np.arange(-(-W // 24))[None, :] * 13) % 40
+    depth = np.repeat(np.repeat(1000 + 60 * cell, 24, 0), 24, 1)[:H, :W].astype(np.uint16)
+    rgb = np.full((H, W, 3), 128, np.uint8)
+    with Context(H, W, max_batch=1) as ctx:
+        pat, _ = ctx.patches(ctx.smooth_depth(depth.astype(np.float32)))[:2]
+        assert pat.max() > 510, pat.max()
+        with pytest.raises(RuntimeError, match="at most 512"):
+            ctx.find_surfaces_batch(depth[None], rgb[None])
+
+
 @pytest.mark.parametrize("r,shape", [(10, (50, 70)), (15, (50, 70)), (15, (24, 40)), (4, (37, 90))])
 def test_rolling_window_on_ragged_and_tiny_frames(oracle, r, shape):
     """Window radii other than 7 on frames whose sides are no multiples of the 32 x 16 tiles, and on a frame smaller than
