@@ -56,6 +56,7 @@ SIGNATURES = {
     "fs_set_timing": (_i, [_vp, _i]),
     "fs_get_tile_labels": (_i, [_vp, _i, _vp] + [_c.POINTER(_i)] * 4),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
+    "fs_get_speculation_counts": (_i, [_vp, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 
 _LIB = None
@@ -266,6 +267,13 @@ class Context:
 
     def set_timing(self, group_mask):
         self._check(self._lib.fs_set_timing(self._h, int(group_mask)))
+
+    def speculation_counts(self):
+        """(held, repeated): one-frame calls whose updates went out ahead of the label count and stood, or had to be
+        run again because the frame did not fit what they were sized for."""
+        held, rep = _c.c_int64(0), _c.c_int64(0)
+        self._check(self._lib.fs_get_speculation_counts(self._h, ctypes.byref(held), ctypes.byref(rep)))
+        return held.value, rep.value
 
     def get_timing(self, group):
         ms, cnt = _d(0), _c.c_int64(0)

@@ -1,6 +1,8 @@
 // C ABI of libfs_hip.so (declared in include/fs_hip.h): context, device buffers
 // and the orchestration of the kernels in k_stencils.hip, k_cc.hip, k_crf.hip.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +48,19 @@ struct fs_ctx {
     bool todo_clean = false;           // its per-frame counters are zero (the chain of kernels leaves them so)
     DevBuf tile_recs, counts;          // per-tile active labels [n][tiles][rec]; counts = nlabels[n] | max_active[n]
     HostBuf counts_host;               // page-locked: nlabels[0..n) then max_active[0..n)
+    // One frame per call: the three updates are enqueued before the label counts reach the host (CrfFrameDesc::spec).
+    // The counts then come through a page-locked word that the first update's first block writes and the host polls
+    // (CrfFrameDesc::publish), not through a copy command that the updates would queue behind.
+    bool speculate = true;                         // FS_NO_SPECULATION=1 switches it off (measurements, tests)
+    hipEvent_t spec_copied = nullptr;
+    HostBuf publish_host;                          // the word
+    DevBuf publish_seq;                            // device word: one-frame calls so far (the kernels count)
+    unsigned publish_expected = 0;                 // ... as the host counts them
+    DevBuf spec_descs;
+    HostBuf spec_descs_host;
+    std::vector<CrfFrameDesc> spec_shadow;         // what spec_descs holds
+    int spec_cap = 0;                              // label channels the Q planes held when the last such launch went out
+    int64_t spec_held = 0, spec_repeated = 0;
     // per-surface statistics (one frame in flight)
     DevBuf st_in, st_work, st_scratch, st_out, st_pool, st_descs, st_lin, st_lab;
     std::vector<StatsFrame> st_descs_host;
@@ -220,6 +235,12 @@ int ensure_frame_buffers(fs_ctx *ctx)
     ctx->todo_clean = false;           // new memory, or another layout (the lists follow max_batch counters)
     ctx->queue_clean = false;
     FS_HIP(ctx->counts_host.ensure(2 * n * sizeof(int32_t)));
+    if (!ctx->publish_seq.p) {
+        FS_HIP(ctx->publish_host.ensure(sizeof(unsigned long long)));
+        *ctx->publish_host.as<unsigned long long>() = 0;
+        FS_HIP(ctx->publish_seq.ensure(sizeof(unsigned)));
+        FS_HIP(hipMemset(ctx->publish_seq.p, 0, sizeof(unsigned)));
+    }
     if (crf_fused_tile_height(ctx->r)) {
         int tx, ty;
         crf_fused_tile_grid(ctx->H, ctx->W, ctx->r, &tx, &ty);
@@ -243,7 +264,7 @@ CcWork cc_work(fs_ctx *ctx)
 
 // smoothed depth -> patches / edges (device), label counts to the host
 int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches64, int32_t *d_patches32, int32_t *d_edges,
-                float *d_scores, uint8_t *d_curv, bool read_counts)
+                float *d_scores, uint8_t *d_curv, int read_counts)      // 0: no, 1: copied and waited for, 2: left to the first update (wait_published_counts)
 {
     const int H = ctx->H, W = ctx->W;
     const float threshold = (float)(0.007003343675404672 * 10.5);   // find_surfaces.py:229
@@ -277,9 +298,30 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
                                    ctx->crf_queue.as<unsigned>(), (int)(kCrfQueueSlots * kCrfQueueBytes / sizeof(unsigned)));
             ctx->queue_clean = true;
         }
-        FS_HIP(hipMemcpyAsync(ctx->counts_host.p, ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        FS_HIP(hipStreamSynchronize(ctx->stream));
+        if (read_counts == 1) {
+            FS_HIP(hipMemcpyAsync(ctx->counts_host.p, ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            FS_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
+    return 0;
+}
+
+// the label counts of a one-frame call whose updates went out ahead of them (launch_crf_speculative) -> ctx->counts_host
+int wait_published_counts(fs_ctx *ctx)
+{
+    const volatile unsigned long long *pub = ctx->publish_host.as<unsigned long long>();
+    const unsigned long long want = ctx->publish_expected & 0xffffu;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long word;
+    for (unsigned spins = 0; ((word = *pub) >> 48) != want; ++spins) {
+        if ((spins & 0xffffu) == 0xffffu) {
+            if (hipError_t e = hipStreamQuery(ctx->stream); e != hipSuccess && e != hipErrorNotReady) return ctx->fail(e, "waiting for the label counts");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return ctx->fail("label counts did not arrive within 30 s");
+        }
+    }
+    int32_t *dst = ctx->counts_host.as<int32_t>();
+    dst[0] = (int32_t)(word & 0xffffffffu);
+    dst[1] = (int32_t)(word >> 32 & 0xffffu);
     return 0;
 }
 
@@ -441,6 +483,69 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     return 0;
 }
 
+
+constexpr int kSpecLabels = 64;                // Q planes a one-frame call allocates before it knows the frame's label count
+constexpr int kSpecClass = 2;                  // kernel variant of the updates launched ahead of the counts (16 channels per tile)
+
+// does a frame with S label channels and max_active listed labels in its fullest tile fit a launch made ahead of the counts?
+bool spec_fits(int S, int max_active, int cap) { return S <= cap && crf_channel_class(std::min(S, max_active + 3)) == kSpecClass; }
+
+// One frame, fused update: `iterations` mean-field updates enqueued behind the kernels that produce the patch labels,
+// before the label count has reached the host.  The updates read the count from ctx->counts (CrfFrameDesc::spec) and
+// leave the frame alone when it does not fit (spec_fits, evaluated by the kernels and, afterwards, by the caller).
+int launch_crf_speculative(fs_ctx *ctx, const uint16_t *d_depth, const int32_t *d_labels32, int iterations, int64_t *d_surfaces)
+{
+    const int H = ctx->H, W = ctx->W;
+    const size_t N = ctx->N();
+    FS_HIP(ctx->qa.ensure((size_t)kSpecLabels * N * sizeof(float)));
+    FS_HIP(ctx->qb.ensure((size_t)kSpecLabels * N * sizeof(float)));
+    ctx->spec_cap = (int)std::min<size_t>(std::min(ctx->qa.cap, ctx->qb.cap) / (N * sizeof(float)), (size_t)kMaxLabels);
+    std::vector<CrfFrameDesc> want((size_t)iterations);
+    for (int it = 0; it < iterations; ++it) {
+        const bool last = it == iterations - 1;
+        CrfFrameDesc &d = want[it];
+        d = CrfFrameDesc{};
+        d.featA = ctx->featA.as<float4>();
+        d.featB = ctx->featB.as<float2>();
+        d.Qin = (it & 1) ? ctx->qb.as<float>() : ctx->qa.as<float>();
+        d.Qout = last ? nullptr : ((it & 1) ? ctx->qa.as<float>() : ctx->qb.as<float>());
+        d.patches = d_labels32;
+        d.depth_raw = d_depth;
+        d.surfaces = last ? d_surfaces : nullptr;
+        d.tile_recs = ctx->tile_recs.as<int32_t>();
+        d.spec = ctx->counts.as<int32_t>();          // n = 1: [0] largest patch label, [1] most listed labels of a tile
+        d.spec_cap = ctx->spec_cap;
+        d.publish = it == 0 ? ctx->publish_host.as<unsigned long long>() : nullptr;
+        d.publish_seq = ctx->publish_seq.as<unsigned>();
+    }
+    // the descriptors change only when a buffer moves or the caller passes other arrays: uploaded then, in stream order
+    // behind the launches that still read the old ones
+    const size_t bytes = want.size() * sizeof(CrfFrameDesc);
+    if (ctx->spec_shadow.size() != want.size() || std::memcmp(ctx->spec_shadow.data(), want.data(), bytes) != 0) {
+        if (ctx->spec_copied) FS_HIP(hipEventSynchronize(ctx->spec_copied));       // the staging block's previous upload
+        else FS_HIP(hipEventCreateWithFlags(&ctx->spec_copied, hipEventDisableTiming));
+        FS_HIP(ctx->spec_descs_host.ensure(bytes));
+        FS_HIP(ctx->spec_descs.ensure(bytes));
+        std::memcpy(ctx->spec_descs_host.p, want.data(), bytes);
+        FS_HIP(hipMemcpyAsync(ctx->spec_descs.p, ctx->spec_descs_host.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(hipEventRecord(ctx->spec_copied, ctx->stream));
+        ctx->spec_shadow = want;
+    }
+    const CrfFrameDesc *dd = ctx->spec_descs.as<CrfFrameDesc>();
+    const CrfGeom geom{H, W, 0, 0, H, W, ctx->r};
+    if (!ctx->queue_clean) FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
+    ctx->queue_clean = false;
+    for (int it = 0; it < iterations; ++it) {
+        ScopedTimer t(ctx, G_ITER);
+        const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
+        unsigned *queue = ctx->crf_queue.as<unsigned>() + (size_t)it * (kCrfQueueBytes / sizeof(unsigned));
+        hipError_t e = launch_crf_iter_fused(dd + it, 1, kSpecClass, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream);
+        if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
+        if (it == 0) ++ctx->publish_expected;        // the launch is out: its first block will count it too
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -475,6 +580,7 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     if (hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
+    if (const char *e = getenv("FS_NO_SPECULATION")) ctx->speculate = e[0] != '1';
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
     // this GPU's copy of the static work space of fs_connected_components_noalloc: looked up here, once per
@@ -489,7 +595,7 @@ void fs_destroy(fs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
+    DevBuf *bufs[] = {&ctx->spec_descs, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin, &ctx->st_lab,
@@ -503,6 +609,9 @@ void fs_destroy(fs_ctx *ctx)
     if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
     for (hipEvent_t e : ctx->pipe_events) (void)hipEventDestroy(e);
     if (ctx->descs_copied) (void)hipEventDestroy(ctx->descs_copied);
+    if (ctx->spec_copied) (void)hipEventDestroy(ctx->spec_copied);
+    ctx->spec_descs_host.release();
+    ctx->publish_host.release();
     ctx->descs_host.release();
     ctx->counts_host.release();
     delete ctx;
@@ -602,6 +711,14 @@ int fs_set_timing(fs_ctx *ctx, int enable)
 {
     if (!ctx) return -1;
     ctx->timing = (unsigned)enable;
+    return 0;
+}
+
+int fs_get_speculation_counts(fs_ctx *ctx, int64_t *held, int64_t *repeated)
+{
+    if (!ctx) return -1;
+    if (held) *held = ctx->spec_held;
+    if (repeated) *repeated = ctx->spec_repeated;
     return 0;
 }
 
@@ -821,6 +938,8 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
     int32_t *edges = d_edges ? d_edges : ctx->edges.as<int32_t>();
     int64_t *surfaces = d_surfaces ? d_surfaces : ctx->surfaces64.as<int64_t>();
     const bool fused_crf = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;     // as run_crf_batch decides
+    // One frame per call: the updates go out before the label count has come back (launch_crf_speculative).
+    const bool speculate = ctx->speculate && n == 1 && fused_crf;
     {
         ScopedTimer t(ctx, G_STENCIL);
         // (the colour half of the fused CRF update's feature records is written on the way: it needs the same depth)
@@ -833,8 +952,12 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
                             crf_angle_feature_scale(ctx->params), n, H, W, ctx->stream);
     }
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
-                    ctx->curv.as<uint8_t>(), true))                                                            // :513
+                    ctx->curv.as<uint8_t>(), speculate ? 2 : 1))                                               // :513
         return -1;
+    if (speculate) {
+        if (launch_crf_speculative(ctx, d_depth, ctx->patches32.as<int32_t>(), 3, surfaces)) return -1;        // :515-532
+        if (wait_published_counts(ctx)) return -1;
+    }
     std::vector<int> S(n), maxa(n);
     const int32_t *counts = ctx->counts_host.as<int32_t>();
     for (int i = 0; i < n; ++i) {
@@ -842,6 +965,14 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
         if (num_surfaces) num_surfaces[i] = ns;
         S[i] = ns + 1;
         maxa[i] = counts[n + i];
+    }
+    // the updates in flight are the frame's if the frame fits them; otherwise they gave up and the regular path runs
+    if (speculate) {
+        if (spec_fits(S[0], maxa[0], ctx->spec_cap)) {
+            ++ctx->spec_held;
+            return 0;
+        }
+        ++ctx->spec_repeated;
     }
     if (run_crf_batch(ctx, n, d_depth, d_rgb, angles, ctx->patches32.as<int32_t>(), S.data(), maxa.data(), 3, surfaces, fused_crf))   // :515-532
         return -1;

@@ -179,8 +179,21 @@ struct CrfFrameDesc {            // one frame of a batched launch (device-reside
     const float2 *featB;         // fused update: [Hi*Wi] (angle0, angle1), or null
     int64_t *surfaces;           // [oh*ow] or null: argmax output
     const int32_t *tile_recs;    // per-tile active-label records or null (every label carried)
+    // Fused update only.  A launch may be enqueued before the frame's label count has reached the host (one frame per
+    // call: the read-back would leave the GPU idle for its round trip).  `spec` then points at the device words
+    // (largest patch label, most listed labels of a tile) that the preceding kernels write; the update derives S from
+    // them and leaves the frame alone unless S <= spec_cap (what the Q planes hold) and every tile's channels fit the
+    // launched kernel variant.  The host evaluates the same test once the words arrive and, if it fails, runs the
+    // update again with what it then knows.  Null: S below is the label count.
+    // publish (with spec, first update only; else null): page-locked word through which the two device words reach the
+    // host, which polls it instead of putting a copy command into the stream (the updates would queue behind it, about
+    // 10 us per call): the launch's first block stores largest label | listed labels << 32 | sequence number << 48, the
+    // sequence number being the incremented device word *publish_seq (so the host can tell this call's word from the last).
+    const int32_t *spec;
+    unsigned long long *publish;
+    unsigned *publish_seq;
     int S;                       // label channels
-    int pad_;
+    int spec_cap;
 };
 struct CrfGeom {                 // common to all frames of a launch
     int Hi, Wi;                  // extent of Q / similarity / feature arrays

@@ -56,6 +56,29 @@ constexpr int MASK_WORDS = kMaxLabels / 32;
 constexpr int REC_MASK = 8, REC_LAB = REC_MASK + MASK_WORDS;
 constexpr int TILE_REC = REC_LAB + kMaxLabels;
 
+// Label channels of a frame for a kernel variant that carries at most `tile_channels` channels per tile; 0 when the
+// descriptor was written ahead of the label count (CrfFrameDesc::spec) and the frame turned out not to fit.
+__device__ __forceinline__ int frame_channels(const CrfFrameDesc &d, int tile_channels)
+{
+    if (!d.spec) return d.S;
+    const int S = d.spec[0] + 2;                              // num_surfaces + 1, num_surfaces = largest patch label + 1
+    const int ce = min(S, d.spec[1] + 3);                     // listed labels + background + representative + "unassigned"
+    return S <= d.spec_cap && ce <= tile_channels ? S : 0;
+}
+
+// First block of a launch made ahead of the label count: hands the two device words to the host (CrfFrameDesc::publish).
+__device__ __forceinline__ void publish_counts(const CrfFrameDesc *descs)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const CrfFrameDesc &d = descs[0];
+    if (!d.spec || !d.publish) return;
+    const unsigned seq = *d.publish_seq + 1u;
+    *d.publish_seq = seq;
+    const unsigned long long word = (unsigned long long)(unsigned)d.spec[0] | (unsigned long long)((unsigned)d.spec[1] & 0xffffu) << 32 |
+                                    (unsigned long long)(seq & 0xffffu) << 48;
+    __hip_atomic_store(d.publish, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Dynamic LDS a kernel instantiation has been allowed so far.  The attribute belongs to (device, function), so
 // the record is kept per device; several contexts (one per GPU, or several host threads) may launch at once.
 struct LdsAllowance {

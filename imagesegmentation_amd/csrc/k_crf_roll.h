@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     // length while idle blocks find the queues empty (one frame: 600 tiles, 512 blocks, a second round for 62 tiles):
     // a small launch claims its next tile only when the window walk is over, in front of the epilogue.
     const bool claim_early = tiles_total > 2u * gridDim.x;
+    if (first) publish_counts(descs);
     if (threadIdx.x == 0) s_ticket = next_tile();
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();
@@ -194,7 +195,13 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
-    const int r = R ? R : g.r, S = d.S;
+    const int r = R ? R : g.r, S = frame_channels(d, NCH * CH);
+    if (S == 0) {                                            // enqueued ahead of the label count, and the frame does not fit
+        __syncthreads();                                     // (every lane has read the ticket)
+        if (threadIdx.x == 0) s_ticket = claim_early ? next_ticket : next_tile();
+        __syncthreads();
+        continue;
+    }
     const int LW = FTW + 2 * r;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ix0 = bx * FTW, iy0 = by * TH;

@@ -265,6 +265,12 @@ int fs_set_timing(fs_ctx *ctx, int group_mask);
  * the tile grid and tile size come back through the other pointers.  Host pointers; synchronises. */
 int fs_get_tile_labels(fs_ctx *ctx, int n, int32_t *listed, int *tiles_x, int *tiles_y, int *tile_w, int *tile_h);
 int fs_get_timing(fs_ctx *ctx, int group, double *total_ms, int64_t *launches);
+/* One-frame calls of fs_find_surfaces_batch(_dev) enqueue the three mean-field updates before the frame's label
+ * count has reached the host (sized for what earlier frames needed, at least 64 label channels and 16 channels per
+ * tile) and repeat them when the frame turns out not to fit; results are the same either way.  held / repeated (may
+ * be NULL) receive how often each happened since the context was created.  No counterpart in the reference
+ * (find_surfaces.py:514-517 computes num_surfaces on the host between the two model calls). */
+int fs_get_speculation_counts(fs_ctx *ctx, int64_t *held, int64_t *repeated);
 
 #ifdef __cplusplus
 }

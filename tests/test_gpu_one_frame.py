@@ -1,0 +1,110 @@
+"""One frame per call: the mean-field updates are enqueued before the label count has come back to the host, which
+receives it through page-locked memory that a kernel writes.  Whatever happens to the guess, the results must be
+those of a context that waits for the count first (FS_NO_SPECULATION=1), bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("patches", "depth_edges", "surfaces", "angles", "vectors", "points_3d")
+
+
+def _plain_context(H, W, **kw):
+    from imagesegmentation_amd._lib import Context
+    old = {k: os.environ.get(k) for k in ("FS_NO_SPECULATION",)}
+    os.environ["FS_NO_SPECULATION"] = "1"
+    try:
+        return Context(H, W, **kw)          # the switches are read when the context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _checker_scene(H, W, cell=20):
+    """10 x 12 flat facets of 20 x 20 pixels side by side at well separated depths, nothing around them: about 120
+    surfaces, and a tile of the CRF update (32 x 16 pixels, labels within 21 pixels count) sees 16 of them."""
+    rng = np.random.Generator(np.random.PCG64(0))
+    i, j = np.mgrid[0:H, 0:W]
+    ci, cj = i // cell, j // cell
+    d = (900 + 260 * ((3 * ci + 5 * cj) % 7)).astype(np.uint16)
+    rgb = rng.integers(30, 226, size=(H // cell + 1, W // cell + 1, 3))[ci, cj].astype(np.uint8)
+    keep = np.zeros((H, W), bool)
+    keep[100:300, 100:340] = True
+    d[~keep] = 0
+    return d, rgb
+
+
+def _same(a, b, what):
+    assert np.array_equal(a["num_surfaces"], b["num_surfaces"]), what
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), f"{what}: {k}"
+
+
+def test_guess_holds_fails_and_recovers():
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_mosaic_scene, make_scene
+    H, W = 480, 640
+    few = make_scene(5, H, W)                              # a couple of dozen surfaces
+    many = make_mosaic_scene(3, H, W, n_patches=100)       # more label channels than a first call allows for
+    dense = _checker_scene(H, W)                           # small facets: a tile lists more labels than 16 channels carry
+    with Context(H, W, max_batch=1) as ctx, _plain_context(H, W, max_batch=1) as plain:
+        assert plain.speculation_counts() == (0, 0)
+        ref_few, ref_many, ref_dense = (plain.find_surfaces_batch(d, c) for d, c in (few, many, dense))
+        assert plain.speculation_counts() == (0, 0)
+        ns_few, ns_many, ns_dense = (int(np.ravel(r["num_surfaces"])[0]) for r in (ref_few, ref_many, ref_dense))
+        assert ns_few + 1 <= 64 < ns_many + 1 and ns_many < ns_dense < 200, (ns_few, ns_many, ns_dense)
+        listed, _ = plain.tile_labels(1)
+        assert listed.max() + 3 > 16, "the dense frame is meant to exceed 16 channels in some tile"
+
+        _same(ctx.find_surfaces_batch(*few), ref_few, "first call")
+        assert ctx.speculation_counts() == (1, 0)
+        _same(ctx.find_surfaces_batch(*many), ref_many, "more channels than the Q planes hold")
+        assert ctx.speculation_counts() == (1, 1)
+        _same(ctx.find_surfaces_batch(*many), ref_many, "the planes have grown")
+        assert ctx.speculation_counts() == (2, 1)
+        # (a buffer that grows takes a quarter more than asked: 1.25 x 104 planes hold this frame's 122 channels)
+        _same(ctx.find_surfaces_batch(*dense), ref_dense, "too many channels in a tile")
+        assert ctx.speculation_counts() == (2, 2)
+        _same(ctx.find_surfaces_batch(*few), ref_few, "back to a frame that fits")
+        assert ctx.speculation_counts() == (3, 2)
+
+
+def test_one_frame_calls_on_the_default_stream():
+    """Device pointers, HIP's legacy default stream, calls back to back without synchronisation in between."""
+    from conftest import DeviceArrays
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W, n = 96, 128, 4
+    d, c = make_batch([41, 42, 43, 44], H, W)
+    dev = DeviceArrays()
+    try:
+        with Context(H, W, max_batch=n) as ctx:
+            ref = ctx.find_surfaces_batch(d, c)
+            ctx.set_stream(None)
+            outs = {"patches": (np.int64, ()), "depth_edges": (np.int32, ()), "surfaces": (np.int64, ()),
+                    "angles": (np.float32, (2,)), "vectors": (np.float32, (3,)), "points_3d": (np.float32, (3,))}
+            size = {k: H * W * int(np.prod(t, dtype=np.int64)) * np.dtype(dt).itemsize for k, (dt, t) in outs.items()}
+            d_depth, d_rgb = dev.upload(d), dev.upload(c)
+            ptr = {k: dev.alloc(n * size[k]) for k in outs}
+            ns = []
+            for i in range(n):
+                ns.append(ctx.find_surfaces_batch_dev(1, d_depth + i * H * W * 2, d_rgb + i * H * W * 3,
+                                                      d_angles=ptr["angles"] + i * size["angles"],
+                                                      d_vectors=ptr["vectors"] + i * size["vectors"],
+                                                      d_points=ptr["points_3d"] + i * size["points_3d"],
+                                                      d_patches=ptr["patches"] + i * size["patches"],
+                                                      d_edges=ptr["depth_edges"] + i * size["depth_edges"],
+                                                      d_surfaces=ptr["surfaces"] + i * size["surfaces"])[0])
+            for k, (dt, t) in outs.items():
+                got = dev.download(ptr[k], np.empty((n, H, W) + t, dt))
+                assert np.array_equal(got, ref[k]), k
+            assert np.array_equal(ns, ref["num_surfaces"])
+            assert ctx.speculation_counts()[0] == n
+            ctx.use_own_stream()
+    finally:
+        dev.free()
