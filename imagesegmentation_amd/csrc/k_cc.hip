@@ -299,11 +299,22 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(int32_t *__restrict__ blo
     }
 }
 
+template <int NT>
+__device__ __forceinline__ int blocks_in_front(const int32_t *__restrict__ bs, int nblk_before, int *s_part);
+
+template <bool SCAN>
 __global__ __launch_bounds__(CC_BLOCK) void cc_rank_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
                                                            const int32_t *__restrict__ blocksum, int32_t *__restrict__ newid,
-                                                           int N, int thr)
+                                                           int N, int thr, int32_t *__restrict__ nlabels, int32_t *__restrict__ clear)
 {
     __shared__ int wsum[CC_BLOCK / 64];
+    __shared__ int s_part[CC_BLOCK / 64];
+    const int32_t *bs = blocksum + (size_t)blockIdx.y * gridDim.x;
+    const int front = SCAN ? blocks_in_front<CC_BLOCK>(bs, blockIdx.x, s_part) : bs[blockIdx.x];
+    if (SCAN && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        nlabels[blockIdx.y] = front + bs[blockIdx.x];
+        if (clear) clear[blockIdx.y] = 0;
+    }
     const size_t fo = (size_t)blockIdx.y * N;
     const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_rank_kernel(const int32_t *__rest
     const unsigned long long b = __ballot(s);
     if (lane == 0) wsum[wv] = __popcll(b);
     __syncthreads();
-    int before = blocksum[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
+    int before = front;
     for (int i = 0; i < wv; ++i) before += wsum[i];
     before += __popcll(b & ((1ull << lane) - 1ull));
     if (p < N) newid[fo + p] = s ? before + 1 : 0;
@@ -385,14 +396,40 @@ __global__ __launch_bounds__(CC_VT) void cc_blocksum4_kernel(const int32_t *__re
     }
 }
 
+// SCAN: blocksum holds the blocks' own survivor counts and every block adds up those of the blocks in front of it
+// itself (a frame has a few hundred blocks: cheaper than a scan kernel between two launches); the frame's last block
+// also writes the label count and clears clear[frame].  Otherwise blocksum holds the exclusive prefix (cc_scan_kernel).
+template <int NT>
+__device__ __forceinline__ int blocks_in_front(const int32_t *__restrict__ bs, int nblk_before, int *s_part)
+{
+    int t = 0;
+    for (int b = threadIdx.x; b < nblk_before; b += NT) t += bs[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) sum += s_part[i];
+    return sum;
+}
+
+template <bool SCAN>
 __global__ __launch_bounds__(CC_VT) void cc_rank4_kernel(const int32_t *__restrict__ parent, const int32_t *__restrict__ count,
                                                          const int32_t *__restrict__ blocksum, int32_t *__restrict__ newid, int N,
-                                                         int thr)
+                                                         int thr, int32_t *__restrict__ nlabels, int32_t *__restrict__ clear)
 {
     __shared__ int wsum[CC_VT / 64];
+    __shared__ int s_part[CC_VT / 64];
     const size_t fo = (size_t)blockIdx.y * N;
     const int p = blockIdx.x * CC_BLOCK + threadIdx.x * 4;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int32_t *bs = blocksum + (size_t)blockIdx.y * gridDim.x;
+    const int front = SCAN ? blocks_in_front<CC_VT>(bs, blockIdx.x, s_part) : bs[blockIdx.x];
+    if (SCAN && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        nlabels[blockIdx.y] = front + bs[blockIdx.x];
+        if (clear) clear[blockIdx.y] = 0;
+    }
     bool s[4] = {false, false, false, false};
     if (p < N) survivors4(parent, count, fo + p, p, thr, s);
     const unsigned long long low = (1ull << lane) - 1ull;
@@ -405,7 +442,7 @@ __global__ __launch_bounds__(CC_VT) void cc_rank4_kernel(const int32_t *__restri
     }
     if (lane == 0) wsum[wv] = t;
     __syncthreads();
-    int run = blocksum[(size_t)blockIdx.y * gridDim.x + blockIdx.x] + mine;
+    int run = front + mine;
     for (int i = 0; i < wv; ++i) run += wsum[i];
     if (p < N) {
         int4 id;
@@ -459,6 +496,8 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
     const int nblk = (int)cc_blocks_per_image(H, W);
     const dim3 grid(nblk, n), block(CC_BLOCK);
     launch_local_and_border<uint8_t, true>(mask, w.parent, w.count, w.newid, n, H, W, st);   // newid holds the local sizes until cc_rank
+    // frames of up to a few thousand blocks: every block of the ranking pass adds up the counts in front of it itself
+    const bool own_scan = nblk <= 4096;
     // four pixels per lane when every frame starts on a 16-byte boundary in all arrays
     const bool vec = N % 4 == 0 && reinterpret_cast<uintptr_t>(w.parent) % 16 == 0 && reinterpret_cast<uintptr_t>(w.count) % 16 == 0 &&
                      reinterpret_cast<uintptr_t>(w.newid) % 16 == 0 && reinterpret_cast<uintptr_t>(labels64) % 16 == 0 &&
@@ -467,15 +506,23 @@ void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_s
         const dim3 block4(CC_VT);
         hipLaunchKernelGGL(cc_sum_sizes4_kernel, grid, block4, 0, st, w.parent, w.count, w.newid, N);
         hipLaunchKernelGGL(cc_blocksum4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
-        hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
-        hipLaunchKernelGGL(cc_rank4_kernel, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
+        if (own_scan) {
+            hipLaunchKernelGGL(cc_rank4_kernel<true>, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive, w.nlabels, w.clear);
+        } else {
+            hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
+            hipLaunchKernelGGL(cc_rank4_kernel<false>, grid, block4, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive, nullptr, nullptr);
+        }
         hipLaunchKernelGGL(cc_relabel4_kernel, grid, block4, 0, st, w.parent, w.newid, labels64, labels32, N);
         return;
     }
     hipLaunchKernelGGL(cc_sum_sizes_kernel, grid, block, 0, st, w.parent, w.count, w.newid, N);
     hipLaunchKernelGGL(cc_blocksum_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, N, min_size_exclusive);
-    hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
-    hipLaunchKernelGGL(cc_rank_kernel, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive);
+    if (own_scan) {
+        hipLaunchKernelGGL(cc_rank_kernel<true>, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive, w.nlabels, w.clear);
+    } else {
+        hipLaunchKernelGGL(cc_scan_kernel, dim3(n), dim3(1024), 0, st, w.blocksum, w.nlabels, w.clear, nblk);
+        hipLaunchKernelGGL(cc_rank_kernel<false>, grid, block, 0, st, w.parent, w.count, w.blocksum, w.newid, N, min_size_exclusive, nullptr, nullptr);
+    }
     hipLaunchKernelGGL(cc_relabel_kernel, grid, block, 0, st, w.parent, w.newid, labels64, labels32, N);
 }
 

@@ -7,6 +7,8 @@
 // with -ffp-contract=off and hipcc's default correctly-rounded fp32 divide/sqrt,
 // so the discrete outputs that depend on float comparisons (curvature mask,
 // depth edges) are bit-identical to an unfused CPU evaluation.
+#include <algorithm>
+
 #include "fs_common.h"
 
 namespace fs {
@@ -305,6 +307,29 @@ __global__ __launch_bounds__(NT) void angle_filter_kernel(const float *__restric
 // precomputed on the host with the same fp32 operations.
 // ---------------------------------------------------------------------------
 // depth(oy, ox) = smoothed depth at the centre's row + oy, column + ox
+// One direction (d0, d1) of the reference's evaluation, one fp32 operation per TF op: curs[k-1] = the running sum
+// `cur` after step k (find_surfaces.py:246-259); the total adds the 32 values direction by direction.
+template <typename Depth>
+__device__ __forceinline__ void curvature_direction_exact(Depth depth, int d0, int d1, float dc, float dfx, float dfy, float (&curs)[4])
+{
+    float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+        const float nx = dfx * (float)k, ny = dfy * (float)k;
+        const float nz = depth(-k * d0, -k * d1);
+        const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
+        const float a1 = (e0 * e0 + e1 * e1) + e2 * e2;
+        const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
+        const float a2 = (g0 * g0 + g1 * g1) + g2 * g2;
+        const float dif1 = sqrtf(a1), dif2 = sqrtf(a2);
+        const float score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
+        cur = cur + score;
+        curs[k - 1] = cur;
+        prevd = dif2;
+        px = nx; py = ny; pz = nz;
+    }
+}
+
 template <bool FAST, typename Depth>
 __device__ __forceinline__ float curvature_total(Depth depth, float dc, float dfx, float dfy)
 {
@@ -338,22 +363,10 @@ __device__ __forceinline__ float curvature_total(Depth depth, float dc, float df
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-        float cur = 0.0f, prevd = 0.0f, px = 0.0f, py = 0.0f, pz = dc;
+        float curs[R];
+        curvature_direction_exact(depth, d0s[d], d1s[d], dc, dfx, dfy, curs);
 #pragma unroll
-        for (int k = 1; k <= R; ++k) {
-            const float nx = dfx * (float)k, ny = dfy * (float)k;
-            const float nz = depth(-k * d0s[d], -k * d1s[d]);
-            const float e0 = nx - px, e1 = ny - py, e2 = nz - pz;
-            const float a1 = (e0 * e0 + e1 * e1) + e2 * e2;
-            const float g0 = nx - 0.0f, g1 = ny - 0.0f, g2 = nz - dc;
-            const float a2 = (g0 * g0 + g1 * g1) + g2 * g2;
-            const float dif1 = sqrtf(a1), dif2 = sqrtf(a2);
-            const float score = div_no_nan(dif1 + prevd, dif2) - 1.0f;
-            cur = cur + score;
-            total = total + cur;
-            prevd = dif2;
-            px = nx; py = ny; pz = nz;
-        }
+        for (int k = 0; k < R; ++k) total = total + curs[k];
     }
     return total;
 }
@@ -427,8 +440,12 @@ __global__ __launch_bounds__(NT) void curvature_mask_kernel(const float *__restr
     mask[i] = dc > 0.001f ? pix : 0;
 }
 
-// The reference's correctly rounded evaluation for the pixels curvature_mask_kernel left undecided: one lane
-// per list entry, depths read from global memory (the entries are scattered over the frame).
+// The reference's correctly rounded evaluation for the pixels curvature_mask_kernel left undecided, depths read from
+// global memory (the entries are scattered over the frame).  Eight lanes per list entry, one per direction: the
+// evaluation is a chain of correctly rounded roots and divisions, and with one lane per entry a frame's few hundred
+// entries kept a handful of waves busy for the length of eight such chains.  The first lane of an entry then adds the
+// 32 running sums in the reference's order (direction by direction), so the total is the same number.
+constexpr int kCurvExactBlocks = 64;      // blocks per frame; they stride over the list
 __global__ __launch_bounds__(256) void curvature_exact_kernel(const float *__restrict__ D, const float *__restrict__ ax,
                                                               const float *__restrict__ ay, float threshold,
                                                               uint8_t *__restrict__ mask, const int32_t *__restrict__ todo,
@@ -436,16 +453,25 @@ __global__ __launch_bounds__(256) void curvature_exact_kernel(const float *__res
 {
     const int32_t *list = todo_list + (size_t)blockIdx.y * todo_cap;
     const int count = min(todo[blockIdx.y], todo_cap);
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count) return;
-    const int p = list[t], r = p / W, c = p - r * W;
     const float *F = D + (size_t)blockIdx.y * H * W;
-    const float dc = F[p];
-    const float dfx = (ax[c] * dc) * 0.5f;
-    const float dfy = (ay[r] * dc) * 0.5f;
-    auto at = [&](int oy, int ox) { return F[p + oy * W + ox]; };   // the centre is at least 4 pixels inside the frame
-    const float total = curvature_total<false>(at, dc, dfx, dfy);
-    mask[(size_t)blockIdx.y * H * W + p] = (total < threshold && dc > 0.001f) ? 1 : 0;
+    const int d = threadIdx.x & 7, lane = threadIdx.x & 63;
+    const int d0 = d == 0 || d == 1 || d == 7 ? 1 : (d >= 3 && d <= 5 ? -1 : 0);     // [1,0],[1,1],[0,1],[-1,1],[-1,0],[-1,-1],[0,-1],[1,-1]
+    const int d1 = d >= 1 && d <= 3 ? 1 : (d >= 5 ? -1 : 0);
+    for (int t = blockIdx.x * 32 + (threadIdx.x >> 3); t < count; t += gridDim.x * 32) {    // the same t in all eight lanes of an entry
+        const int p = list[t], r = p / W, c = p - r * W;
+        const float dc = F[p];
+        const float dfx = (ax[c] * dc) * 0.5f;
+        const float dfy = (ay[r] * dc) * 0.5f;
+        auto at = [&](int oy, int ox) { return F[p + oy * W + ox]; };   // the centre is at least 4 pixels inside the frame
+        float curs[4];
+        curvature_direction_exact(at, d0, d1, dc, dfx, dfy, curs);
+        float total = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) total = total + __shfl(curs[k], (lane & ~7) + dd);
+        if (d == 0) mask[(size_t)blockIdx.y * H * W + p] = (total < threshold && dc > 0.001f) ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -561,7 +587,7 @@ bool launch_curvature_mask(const float *D, const float *ax, const float *ay, flo
     if (!todo_zeroed) (void)hipMemsetAsync(todo, 0, (size_t)todo_frames * sizeof(int32_t), st);
     hipLaunchKernelGGL(curvature_mask_kernel, tile_grid(n, H, W), dim3(NT), 0, st, D, ax, ay, threshold, mask, scores, todo, lists, todo_cap,
                        H, W);
-    hipLaunchKernelGGL(curvature_exact_kernel, dim3((todo_cap + 255) / 256, n), dim3(256), 0, st, D, ax, ay, threshold, mask, todo, lists,
+    hipLaunchKernelGGL(curvature_exact_kernel, dim3(std::min(kCurvExactBlocks, (todo_cap + 31) / 32), n), dim3(256), 0, st, D, ax, ay, threshold, mask, todo, lists,
                        todo_cap, H, W);
     return true;
 }
