@@ -152,8 +152,8 @@ def committed_counters(workload, r):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="osd", choices=["osd", "synthetic640", "synthetic1280", "mosaic1280", "stream640"])
     ap.add_argument("--stage", default="find_surfaces", choices=["find_surfaces", "stats"])
     ap.add_argument("--frames", type=int, default=0, help="frames per step and GPU (default 111; 16 for 1280x960; 100 for the stream)")
@@ -254,6 +254,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    host_leg = None
+    if not host_main and not args.no_host_leg:
+        # the same stage host buffer to host buffer (page-locked): inputs 1.5 MB and the six output arrays 15.8 MB per
+        # 640x480 frame cross PCIe inside the timed region; with N > 1 every rank does so at the same time, which is
+        # where ranks of one node compete (host memory, PCIe root complexes) while the HBM-resident loop cannot show it
+        step_host()
+        barrier()
+        hs = max(2, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(hs):
+            step_host()
+        barrier()
+        hdt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([hdt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hdt = float(t.item())
+        per_frame_bytes = H * W * (2 + 3) + H * W * (8 + 12 + 12 + 8 + 4 + 8)
+        host_leg = {"value": world * n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
+                    "bytes_per_frame": per_frame_bytes, "pcie_gbs": hs * world * n * per_frame_bytes / hdt / 1e9,
+                    "note": "page-locked host arrays in, six page-locked output arrays back; measured after the headline loop on "
+                            "all ranks at once (whole-job rate, max time over ranks)"}
+
     if rank == 0:
         S = ns.astype(np.int64) + 1                       # label channels per frame
         N = H * W
@@ -306,22 +329,8 @@ def main():
                                  "staged channel); algorithmic_tflops prices all S channels of every pixel and may exceed the peak "
                                  "because the kernel carries only the labels near a tile; busy = VALU-issue share of the kernel's "
                                  "duration from the committed SQ counters"}}
-        if not host_main and not args.no_host_leg and world == 1:
-            # the same stage host buffer to host buffer (page-locked): inputs 1.5 MB and the six output arrays 15.8 MB per
-            # 640x480 frame cross PCIe inside the timed region
-            step_host()
-            torch.cuda.synchronize(dev)
-            hs = max(2, min(args.steps, 5))
-            t1 = time.perf_counter()
-            for _ in range(hs):
-                step_host()
-            torch.cuda.synchronize(dev)
-            hdt = time.perf_counter() - t1
-            per_frame_bytes = N * (2 + 3) + N * (8 + 12 + 12 + 8 + 4 + 8)
-            out["value_host_buffers"] = {"value": n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
-                                         "bytes_per_frame": per_frame_bytes, "pcie_gbs": hs * n * per_frame_bytes / hdt / 1e9,
-                                         "note": "page-locked host arrays in, six page-locked output arrays back; measured after the "
-                                                 "headline loop, N = 1 only (--workload stream640 is the N > 1 form)"}
+        if host_leg is not None:
+            out["value_host_buffers"] = host_leg
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(depth, rgb, r)
             out["cpu_baseline_b0"] = cpu_baseline_b0(depth, rgb, r)
