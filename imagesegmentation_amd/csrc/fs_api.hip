@@ -2,7 +2,6 @@
 // and the orchestration of the kernels in k_stencils.hip, k_cc.hip, k_crf.hip.
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -311,13 +310,15 @@ int wait_published_counts(fs_ctx *ctx)
 {
     const volatile unsigned long long *pub = ctx->publish_host.as<unsigned long long>();
     const unsigned long long want = ctx->publish_expected & 0xffffu;
-    const auto t0 = std::chrono::steady_clock::now();
     unsigned long long word;
     for (unsigned spins = 0; ((word = *pub) >> 48) != want; ++spins) {
-        if ((spins & 0xffffu) == 0xffffu) {
-            if (hipError_t e = hipStreamQuery(ctx->stream); e != hipSuccess && e != hipErrorNotReady) return ctx->fail(e, "waiting for the label counts");
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return ctx->fail("label counts did not arrive within 30 s");
-        }
+        if ((spins & 0xffffu) != 0xffffu) continue;
+        // now and then: is the stream still at work?  Once it has drained, the word is either there or will never come.
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) return ctx->fail(e, "waiting for the label counts");
+        if (((word = *pub) >> 48) != want) return ctx->fail("the label counts did not arrive although the stream has drained");
+        break;
     }
     int32_t *dst = ctx->counts_host.as<int32_t>();
     dst[0] = (int32_t)(word & 0xffffffffu);

@@ -41,6 +41,8 @@ __device__ __forceinline__ void wave_histogram_add(uint32_t *__restrict__ hist, 
 {
     unsigned long long todo = __ballot(active);
     const int lane = threadIdx.x & 63;
+    // (rounds bounded at three, the remaining lanes adding their own counts, measured a third slower on the OSD frames:
+    // the atomics, not the rounds, are what the pass waits for)
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t key = __shfl(idx, leader);
@@ -424,32 +426,44 @@ __global__ __launch_bounds__(SB) void stats_finalize_kernel(const StatsFrame *__
     double *__restrict__ out_color = f.hist_color_out, *__restrict__ out_angle = f.hist_angle_out, *__restrict__ out_texture = f.hist_texture_out;
     double *__restrict__ out_avg_angles = f.avg_angles;
     float *__restrict__ out_extent = f.depth_extend;
-    const size_t i = (size_t)blockIdx.x * SB + threadIdx.x;
-    const size_t n_color = (size_t)256 * 256 * S, n_angle = (size_t)40 * 40 * S, n_tex = (size_t)S * T;
+    // (the largest index is 256 * 256 * kMaxLabels < 2^32: label and bin come from 32-bit divisions, a 64-bit one costs
+    // several times the rest of the element's work; a bin nobody fell into is 0 without its float64 division)
+    const uint32_t i = blockIdx.x * (uint32_t)SB + threadIdx.x;
+    const uint32_t n_color = 256u * 256u * (uint32_t)S, n_angle = 40u * 40u * (uint32_t)S, n_tex = (uint32_t)S * (uint32_t)T;
     if (i < n_color) {
-        const int s = (int)(i % S);
-        double norm = (double)cnt[s] / 10;
-        if (norm == 0) norm = 1;
-        out_color[i] = (double)hist_color[i] / norm;
+        const uint32_t h = hist_color[i];
+        double v = 0.0;
+        if (h != 0u) {
+            const uint32_t s = i % (uint32_t)S;
+            double norm = (double)cnt[s] / 10;
+            if (norm == 0) norm = 1;
+            v = (double)h / norm;
+        }
+        out_color[i] = v;
     }
     if (i < n_angle) {
-        const int s = (int)(i % S);
-        double pc = (double)cnt[S + s];
-        if (pc == 0) pc = 1;
-        out_angle[i] = (double)hist_angle[i] / (pc / 10);
+        const uint32_t h = hist_angle[i];
+        double v = 0.0;
+        if (h != 0u) {
+            const uint32_t s = i % (uint32_t)S;
+            double pc = (double)cnt[S + s];
+            if (pc == 0) pc = 1;
+            v = (double)h / (pc / 10);
+        }
+        out_angle[i] = v;
     }
     if (i < n_tex) {
-        const int s = (int)(i / T);
+        const uint32_t s = i / (uint32_t)T;
         double c = (double)tex_cnt[s];
         if (c == 0) c = 1;
         out_texture[i] = tex_sum[i] / c * 10;
     }
-    if (i < (size_t)2 * S) {
+    if (i < 2u * (uint32_t)S) {
         double pc = (double)cnt[S + i / 2];
         if (pc == 0) pc = 1;
         out_avg_angles[i] = angle_sum[i] / pc;
     }
-    if (i < (size_t)8 * S) {
+    if (i < 8u * (uint32_t)S) {
         const uint32_t e = extent[i];
         out_extent[i] = (i & 1) ? (e == 0u ? -INFINITY : dec_f32(e)) : (e == ~0u ? INFINITY : dec_f32(e));
     }

@@ -36,3 +36,29 @@ def test_all_osd_frames_in_one_batch():
             assert not (dis & ~tie).any(), f"frame {i}: {int((dis & ~tie).sum())} label differences that are not ties"
         worst = min(worst, 1.0 - dis.mean())
     assert worst >= 0.999, worst
+
+
+def test_all_osd_frames_one_per_call():
+    """The same 111 frames one per call (what the reference's in-memory callers do, find_surface_model()(x)): every call
+    launches its mean-field updates ahead of the label count.  The results are the batch's, bit for bit, and the guess
+    fails only on the frames whose label count exceeds what the context had allocated until then."""
+    g = np.load(GOLDEN)
+    n = len(g["num_surfaces"])
+    frames = [osd_frame(i) for i in range(n)]
+    d = np.stack([f[0] for f in frames]).astype(np.uint16)
+    c = np.stack([f[1] for f in frames]).astype(np.uint8)
+    from imagesegmentation_amd._lib import Context
+    with Context(480, 640, max_batch=n) as ctx:
+        batch = ctx.find_surfaces_batch(d, c)
+    with Context(480, 640, max_batch=1) as ctx:
+        for i in range(n):
+            one = ctx.find_surfaces_batch(d[i], c[i])
+            assert one["num_surfaces"] == g["num_surfaces"][i], i
+            for k in ("patches", "depth_edges", "surfaces", "angles", "vectors", "points_3d"):
+                assert np.array_equal(one[k], batch[k][i]), (i, k)
+        held, repeated = ctx.speculation_counts()
+    assert held + repeated == n
+    # the planes start at 64 channels and grow by a quarter beyond what a frame needs: one growth step (OSD's largest
+    # frame has 65 channels) at most
+    assert repeated <= 1, (held, repeated)
+    print(f"one frame per call: the early launch stood for {held} of {n} frames")
