@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include "../../include/fs_hip.h"
 #include "fs_common.h"
@@ -51,7 +52,9 @@ struct fs_ctx {
     // The counts then come through a page-locked word that the first update's first block writes and the host polls
     // (CrfFrameDesc::publish), not through a copy command that the updates would queue behind.
     bool speculate = true;                         // FS_NO_SPECULATION=1 switches it off (measurements, tests)
-    hipEvent_t spec_copied = nullptr;
+    hipEvent_t spec_copied = nullptr, counts_copied = nullptr;
+    hipEvent_t early_events[2] = {nullptr, nullptr};   // host-buffer calls of one chunk: outputs leave as they are completed
+    bool early_downloads = true;                   // FS_NO_EARLY_DOWNLOADS=1 switches that off (measurements)
     HostBuf publish_host;                          // the word
     DevBuf publish_seq;                            // device word: one-frame calls so far (the kernels count)
     unsigned publish_expected = 0;                 // ... as the host counts them
@@ -263,7 +266,7 @@ CcWork cc_work(fs_ctx *ctx)
 
 // smoothed depth -> patches / edges (device), label counts to the host
 int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches64, int32_t *d_patches32, int32_t *d_edges,
-                float *d_scores, uint8_t *d_curv, int read_counts)      // 0: no, 1: copied and waited for, 2: left to the first update (wait_published_counts)
+                float *d_scores, uint8_t *d_curv, int read_counts)      // 0: no, 1: copied and waited for, 2: left to the first update (wait_published_counts), 3: copied, counts_copied marks the arrival
 {
     const int H = ctx->H, W = ctx->W;
     const float threshold = (float)(0.007003343675404672 * 10.5);   // find_surfaces.py:229
@@ -297,9 +300,14 @@ int run_patches(fs_ctx *ctx, int n, const float *d_smoothed, int64_t *d_patches6
                                    ctx->crf_queue.as<unsigned>(), (int)(kCrfQueueSlots * kCrfQueueBytes / sizeof(unsigned)));
             ctx->queue_clean = true;
         }
-        if (read_counts == 1) {
+        if (read_counts == 1 || read_counts == 3) {
             FS_HIP(hipMemcpyAsync(ctx->counts_host.p, ctx->counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-            FS_HIP(hipStreamSynchronize(ctx->stream));
+            if (read_counts == 1) {
+                FS_HIP(hipStreamSynchronize(ctx->stream));
+            } else {
+                if (!ctx->counts_copied) FS_HIP(hipEventCreateWithFlags(&ctx->counts_copied, hipEventDisableTiming));
+                FS_HIP(hipEventRecord(ctx->counts_copied, ctx->stream));
+            }
         }
     }
     return 0;
@@ -582,6 +590,7 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
         hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (const char *e = getenv("FS_NO_SPECULATION")) ctx->speculate = e[0] != '1';
+    if (const char *e = getenv("FS_NO_EARLY_DOWNLOADS")) ctx->early_downloads = e[0] != '1';
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
     // this GPU's copy of the static work space of fs_connected_components_noalloc: looked up here, once per
@@ -611,6 +620,9 @@ void fs_destroy(fs_ctx *ctx)
     for (hipEvent_t e : ctx->pipe_events) (void)hipEventDestroy(e);
     if (ctx->descs_copied) (void)hipEventDestroy(ctx->descs_copied);
     if (ctx->spec_copied) (void)hipEventDestroy(ctx->spec_copied);
+    if (ctx->counts_copied) (void)hipEventDestroy(ctx->counts_copied);
+    for (hipEvent_t e : ctx->early_events)
+        if (e) (void)hipEventDestroy(e);
     ctx->spec_descs_host.release();
     ctx->publish_host.release();
     ctx->descs_host.release();
@@ -924,9 +936,15 @@ int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, 
     return 0;
 }
 
-int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
-                               float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges, int64_t *d_surfaces,
-                               int32_t *num_surfaces)
+}  // extern "C"
+
+namespace {
+// The stage on n frames resident in device memory.  after_stage (may be empty) is called when the kernels that
+// complete a group of outputs have been enqueued: 0 = angles, vectors, points; 1 = patches, edges.
+using StageHook = std::function<int(int)>;
+int find_surfaces_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles, float *d_vectors,
+                      float *d_points, int64_t *d_patches, int32_t *d_edges, int64_t *d_surfaces, int32_t *num_surfaces,
+                      const StageHook &after_stage)
 {
     if (check_batch(ctx, n)) return -1;
     if (!ctx->have_params) return ctx->fail("fs_find_surfaces: call fs_set_gauss_params first");
@@ -952,9 +970,15 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
         launch_angle_filter(ctx->raw.as<float>(), ctx->smoothed.as<float>(), angles, fused_crf ? ctx->featB.p : nullptr,
                             crf_angle_feature_scale(ctx->params), n, H, W, ctx->stream);
     }
+    if (after_stage && after_stage(0)) return -1;
     if (run_patches(ctx, n, ctx->smoothed.as<float>(), patches, ctx->patches32.as<int32_t>(), edges, nullptr,
-                    ctx->curv.as<uint8_t>(), speculate ? 2 : 1))                                               // :513
+                    ctx->curv.as<uint8_t>(), speculate ? 2 : (after_stage ? 3 : 1)))                           // :513
         return -1;
+    if (after_stage && after_stage(1)) return -1;
+    if (!speculate && after_stage) {
+        // (the hook's commands went in between the count copy and its wait)
+        FS_HIP(hipEventSynchronize(ctx->counts_copied));
+    }
     if (speculate) {
         if (launch_crf_speculative(ctx, d_depth, ctx->patches32.as<int32_t>(), 3, surfaces)) return -1;        // :515-532
         if (wait_published_counts(ctx)) return -1;
@@ -979,6 +1003,17 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
         return -1;
     FS_HIP(hipGetLastError());
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
+                               float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges, int64_t *d_surfaces,
+                               int32_t *num_surfaces)
+{
+    return find_surfaces_dev(ctx, n, d_depth, d_rgb, d_angles, d_vectors, d_points, d_patches, d_edges, d_surfaces, num_surfaces, StageHook());
 }
 
 int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint8_t *rgb, float *angles, float *vectors,
@@ -1008,25 +1043,48 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
     };
     // the previous call's kernels may still read the input buffers when the caller drives the stream itself
     FS_HIP(hipStreamSynchronize(ctx->stream));
+    const bool early = chunks == 1 && ctx->early_downloads;
+    for (hipEvent_t &e : ctx->early_events)
+        if (early && !e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (upload(0)) return -1;
     for (int k = 0; k < chunks; ++k) {
         const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
         if (k + 1 < chunks && upload(k + 1)) return -1;
         FS_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[2 * k], 0));
-        if (fs_find_surfaces_batch_dev(ctx, (int)cn, ctx->depth16.as<uint16_t>() + f0 * N, ctx->rgb8.as<uint8_t>() + f0 * N * 3,
-                                       ctx->angles.as<float>() + f0 * N * 2, ctx->normals.as<float>() + f0 * N * 3,
-                                       ctx->points.as<float>() + f0 * N * 3, ctx->patches64.as<int64_t>() + f0 * N,
-                                       ctx->edges.as<int32_t>() + f0 * N, ctx->surfaces64.as<int64_t>() + f0 * N,
-                                       num_surfaces ? num_surfaces + f0 : nullptr))
+        const size_t px = cn * N, o = f0 * N;
+        // A call of one chunk has nothing to overlap its downloads with but its own kernels: each group of outputs
+        // starts its way to the host as soon as the kernels that complete it are enqueued (normals, angles and points
+        // after the angle filter, patches and edges after the components), and only the labels wait for the updates.
+        // With several chunks the downloads of a chunk run beside the kernels of the next one anyway.
+        StageHook hook;
+        if (early) hook = [&](int stage) -> int {
+            FS_HIP(hipEventRecord(ctx->early_events[stage], ctx->stream));
+            FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->early_events[stage], 0));
+            if (stage == 0) {
+                if (angles) FS_HIP(hipMemcpyAsync(angles + o * 2, ctx->angles.as<float>() + o * 2, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+            } else {
+                if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+            }
+            return 0;
+        };
+        if (find_surfaces_dev(ctx, (int)cn, ctx->depth16.as<uint16_t>() + f0 * N, ctx->rgb8.as<uint8_t>() + f0 * N * 3,
+                              ctx->angles.as<float>() + f0 * N * 2, ctx->normals.as<float>() + f0 * N * 3,
+                              ctx->points.as<float>() + f0 * N * 3, ctx->patches64.as<int64_t>() + f0 * N,
+                              ctx->edges.as<int32_t>() + f0 * N, ctx->surfaces64.as<int64_t>() + f0 * N,
+                              num_surfaces ? num_surfaces + f0 : nullptr, hook))
             return -1;
         FS_HIP(hipEventRecord(ctx->pipe_events[2 * k + 1], ctx->stream));
         FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->pipe_events[2 * k + 1], 0));
-        const size_t px = cn * N, o = f0 * N;
-        if (angles) FS_HIP(hipMemcpyAsync(angles + o * 2, ctx->angles.as<float>() + o * 2, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
-        if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
-        if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
-        if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
-        if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (!early) {
+            if (angles) FS_HIP(hipMemcpyAsync(angles + o * 2, ctx->angles.as<float>() + o * 2, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+            if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+            if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
+            if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+            if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+        }
         if (surfaces) FS_HIP(hipMemcpyAsync(surfaces + o, ctx->surfaces64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
     }
     FS_HIP(hipStreamSynchronize(ctx->out_stream));
