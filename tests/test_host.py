@@ -277,3 +277,12 @@ def test_png_reader_equals_pil(tmp_path):
     Image.fromarray(noisy[..., 0]).convert("P").save(str(tmp_path / "pal.png"))
     assert L._png_plain(str(tmp_path / "pal.png")) is None
     assert np.array_equal(L.read_png(str(tmp_path / "pal.png")), np.asarray(Image.open(str(tmp_path / "pal.png"))))
+
+
+def test_main_entry_point_runs_the_whole_data_set(monkeypatch):
+    """main.find_surfaces_for_dataset (main.py:25-26): every index of the data set, results saved, nothing plotted."""
+    from imagesegmentation_amd import find_surfaces, main
+    calls = []
+    monkeypatch.setattr(find_surfaces, "find_surfaces_for_indices", lambda indices, **kw: calls.append((list(indices), kw)))
+    main.find_surfaces_for_dataset()
+    assert calls == [(list(range(111)), {"save_data": True, "plot_result": False})]
