@@ -12,6 +12,10 @@
 
 using namespace fs;
 
+#ifndef FS_STAGE_PAGEABLE
+#define FS_STAGE_PAGEABLE 1
+#endif
+
 namespace {
 thread_local std::string g_create_error;   // fs_create has no context to hold its message yet
 
@@ -53,9 +57,14 @@ struct fs_ctx {
     // (CrfFrameDesc::publish), not through a copy command that the updates would queue behind.
     bool speculate = true;                         // FS_NO_SPECULATION=1 switches it off (measurements, tests)
     hipEvent_t spec_copied = nullptr, counts_copied = nullptr;
+    hipEvent_t stats_up_events[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and for its four groups of inputs
+    hipEvent_t stats_events[3] = {nullptr, nullptr, nullptr};   // per-frame statistics: the same for its three groups of outputs
     hipEvent_t early_events[2] = {nullptr, nullptr};   // host-buffer calls of one chunk: outputs leave as they are completed
     bool early_downloads = true;                   // FS_NO_EARLY_DOWNLOADS=1 switches that off (measurements)
     HostBuf publish_host;                          // the word
+    HostBuf frames_in_host;                        // frames of a small host-buffer call that arrive in pageable memory
+    HostBuf stats_in_host;                         // ... and its inputs that arrive in pageable memory, on their way up
+    HostBuf stats_small_host;                      // per-frame statistics: the small outputs on their way to the caller's arrays
     DevBuf publish_seq;                            // device word: one-frame calls so far (the kernels count)
     unsigned publish_expected = 0;                 // ... as the host counts them
     DevBuf spec_descs;
@@ -118,6 +127,17 @@ struct ScopedTimer {
         if (ep) (void)hipEventRecord(ep->b, c->stream);
     }
 };
+
+// page-locked host memory (hipHostMalloc, hipHostRegister) as opposed to ordinary pageable memory
+bool host_memory_is_page_locked(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();            // an address the runtime does not know: pageable
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 
 int set_device(fs_ctx *ctx)
 {
@@ -623,8 +643,15 @@ void fs_destroy(fs_ctx *ctx)
     if (ctx->counts_copied) (void)hipEventDestroy(ctx->counts_copied);
     for (hipEvent_t e : ctx->early_events)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->stats_events)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->stats_up_events)
+        if (e) (void)hipEventDestroy(e);
     ctx->spec_descs_host.release();
     ctx->publish_host.release();
+    ctx->stats_small_host.release();
+    ctx->stats_in_host.release();
+    ctx->frames_in_host.release();
     ctx->descs_host.release();
     ctx->counts_host.release();
     delete ctx;
@@ -1034,10 +1061,24 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pipe_events.push_back(e);
     }
+    // Frames of a small call that arrive in pageable memory are copied into page-locked memory first (the runtime's own
+    // path for pageable sources holds the calling thread far longer than a memcpy of the same bytes); a large call is
+    // expected to bring page-locked arrays (fs_host_alloc) and is passed through as it is.
+    const uint16_t *depth_src = depth;
+    const uint8_t *rgb_src = rgb;
+    if (chunks == 1 && FS_STAGE_PAGEABLE) {
+        const bool dl = host_memory_is_page_locked(depth), cl = host_memory_is_page_locked(rgb);
+        if (!dl || !cl) {
+            FS_HIP(ctx->frames_in_host.ensure((size_t)n * N * 5));
+            char *stage = ctx->frames_in_host.as<char>();
+            if (!dl) { std::memcpy(stage, depth, (size_t)n * N * 2); depth_src = reinterpret_cast<const uint16_t *>(stage); }
+            if (!cl) { std::memcpy(stage + (size_t)n * N * 2, rgb, (size_t)n * N * 3); rgb_src = reinterpret_cast<const uint8_t *>(stage + (size_t)n * N * 2); }
+        }
+    }
     auto upload = [&](int k) -> int {
         const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
-        FS_HIP(hipMemcpyAsync(ctx->depth16.as<uint16_t>() + f0 * N, depth + f0 * N, cn * N * 2, hipMemcpyHostToDevice, ctx->in_stream));
-        FS_HIP(hipMemcpyAsync(ctx->rgb8.as<uint8_t>() + f0 * N * 3, rgb + f0 * N * 3, cn * N * 3, hipMemcpyHostToDevice, ctx->in_stream));
+        FS_HIP(hipMemcpyAsync(ctx->depth16.as<uint16_t>() + f0 * N, depth_src + f0 * N, cn * N * 2, hipMemcpyHostToDevice, ctx->in_stream));
+        FS_HIP(hipMemcpyAsync(ctx->rgb8.as<uint8_t>() + f0 * N * 3, rgb_src + f0 * N * 3, cn * N * 3, hipMemcpyHostToDevice, ctx->in_stream));
         FS_HIP(hipEventRecord(ctx->pipe_events[2 * k], ctx->in_stream));
         return 0;
     };
@@ -1158,6 +1199,10 @@ void stats_output_sizes(size_t N, size_t S, size_t T, size_t sizes[kStatsOutputs
     for (int k = 0; k < kStatsOutputs; ++k) sizes[k] = v[k];
 }
 
+// Outputs of at most this many bytes travel to a host caller together (one copy into page-locked memory, then a
+// memcpy each): a copy command of their own costs each of them 30-70 us whatever its size, longer than any kernel here.
+bool stats_small_output(size_t bytes) { return bytes <= ((size_t)512 << 10); }
+
 struct StatsInputs {                 // device pointers, frames back to back
     const int64_t *surfaces, *patches;
     const int32_t *edges;
@@ -1172,8 +1217,9 @@ struct StatsInputs {                 // device pointers, frames back to back
 // user_out are device pointers (arrays of all frames back to back, frame i's part sized by S[i]); outputs the caller
 // did not ask for go to the context's staging buffer.  od[k] receives the device address of output k, out_bytes[k] its
 // total size.  Synchronises once to read the error flag.
+// after_stage: see launch_surface_stats_batch; od and out_bytes are filled in before the first call of it.
 int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, int T, const StatsInputs &in, void *const user_out[kStatsOutputs],
-                       char *od[kStatsOutputs], size_t out_bytes[kStatsOutputs])
+                       char *od[kStatsOutputs], size_t out_bytes[kStatsOutputs], const StatsStageHook &after_stage = StatsStageHook())
 {
     const int H = ctx->H, W = ctx->W;
     const size_t N = ctx->N();
@@ -1215,10 +1261,13 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
     char *p = ctx->st_out.as<char>();
     int *d_err = reinterpret_cast<int *>(p);
     p += 256;
-    for (int k = 0; k < kStatsOutputs; ++k) {
-        if (user_out[k]) od[k] = static_cast<char *>(user_out[k]);
-        else { od[k] = p; p += up(out_bytes[k]); }
-    }
+    // staged outputs: the small ones first and next to each other, so that a caller on the host can fetch them all with
+    // one copy (stats_small_output)
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < kStatsOutputs; ++k) {
+            if (user_out[k]) { od[k] = static_cast<char *>(user_out[k]); continue; }
+            if (stats_small_output(out_bytes[k]) == (pass == 0)) { od[k] = p; p += up(out_bytes[k]); }
+        }
     StatsBatchWork w{};
     {
         char *q = ctx->st_work.as<char>();
@@ -1268,7 +1317,7 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
         f.depth_extend = reinterpret_cast<float *>(at(14));
     }
     FS_HIP(hipMemcpyAsync(ctx->st_descs.p, fh.data(), (size_t)n * sizeof(StatsFrame), hipMemcpyHostToDevice, ctx->stream));
-    hipError_t e = launch_surface_stats_batch(ctx->st_descs.as<StatsFrame>(), fh.data(), n, w, H, W, T, ctx->stream);
+    hipError_t e = launch_surface_stats_batch(ctx->st_descs.as<StatsFrame>(), fh.data(), n, w, H, W, T, ctx->stream, after_stage);
     if (e != hipSuccess) return ctx->fail(e, (std::string(who) + ": launch").c_str());
     int err = 0;
     FS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1317,8 +1366,35 @@ int surface_stats_host(fs_ctx *ctx, const char *who, int num_surfaces, const int
     char *p = ctx->st_in.as<char>();
     for (int i = 0; i < 8; ++i) {
         in_dev[i] = p;
-        if (in_sizes[i]) FS_HIP(hipMemcpyAsync(p, in_host[i], in_sizes[i], hipMemcpyHostToDevice, ctx->stream));
         p += up8(in_sizes[i]);
+    }
+    // The inputs go up on the upload stream in the order the kernels want them (colours for the conversion, the two
+    // label images for the relabelling, the points for the centroids, the rest for the accumulation pass), and the
+    // kernels wait for their group only: most of the 13 MB travel beside the first half of the kernel chain.
+    // (The previous call ended with both streams drained: nothing still reads these buffers.)
+    for (hipEvent_t &e : ctx->stats_up_events)
+        if (!e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // An array in ordinary (pageable) memory is first copied into page-locked memory here: the runtime's own path for
+    // such a source held the calling thread for 340 us per 0.9 MB colour image.
+    size_t pageable = 0;
+    bool locked[8];
+    for (int i = 0; i < 8; ++i) {
+        locked[i] = !in_sizes[i] || host_memory_is_page_locked(in_host[i]);
+        if (!locked[i]) pageable += up8(in_sizes[i]);
+    }
+    FS_HIP(ctx->stats_in_host.ensure(pageable));
+    char *stage = ctx->stats_in_host.as<char>();
+    const int up_order[8] = {6, 0, 1, 3, 2, 4, 5, 7}, up_group[8] = {0, 1, 1, 2, 3, 3, 3, 3};
+    for (int k = 0; k < 8; ++k) {
+        const int i = up_order[k];
+        const void *src = in_host[i];
+        if (!locked[i]) {
+            std::memcpy(stage, in_host[i], in_sizes[i]);
+            src = stage;
+            stage += up8(in_sizes[i]);
+        }
+        if (in_sizes[i]) FS_HIP(hipMemcpyAsync(in_dev[i], src, in_sizes[i], hipMemcpyHostToDevice, ctx->in_stream));
+        if (k == 7 || up_group[k + 1] != up_group[k]) FS_HIP(hipEventRecord(ctx->stats_up_events[up_group[k]], ctx->in_stream));
     }
     StatsInputs in{};
     in.surfaces = reinterpret_cast<const int64_t *>(in_dev[0]);
@@ -1333,11 +1409,48 @@ int surface_stats_host(fs_ctx *ctx, const char *who, int num_surfaces, const int
     void *const none[kStatsOutputs] = {};
     char *od[kStatsOutputs];
     size_t out_sizes[kStatsOutputs];
-    if (surface_stats_core(ctx, who, 1, &S, T, in, none, od, out_sizes)) return -1;
+    // Each group of outputs starts its way to the host when the kernels that complete it have been enqueued (the
+    // converted colours after the first kernel, the images and point lists after the component pass, the histograms
+    // at the end), on the download stream beside the kernels that follow; the downloads of a frame's 27 MB otherwise
+    // take longer than all its kernels.
+    const int stage_of[kStatsOutputs] = {1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2};
+    hipError_t hook_error = hipSuccess;
+    for (hipEvent_t &e : ctx->stats_events)
+        if (!e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    size_t small_lo = 0, small_hi = 0;                      // extent of the small outputs in the staging buffer (device), bytes from od[first]
+    char *small_base = nullptr;
+    auto hook = [&](int stage) {
+        auto ok = [&](hipError_t e) { if (e != hipSuccess && hook_error == hipSuccess) hook_error = e; return e == hipSuccess; };
+        if (stage >= 10) {                                  // a group of inputs is about to be read
+            ok(hipStreamWaitEvent(ctx->stream, ctx->stats_up_events[stage - 10], 0));
+            return;
+        }
+        if (!ok(hipEventRecord(ctx->stats_events[stage], ctx->stream)) || !ok(hipStreamWaitEvent(ctx->out_stream, ctx->stats_events[stage], 0))) return;
+        if (stage == 0 && in.lab_out) ok(hipMemcpyAsync(lab_out, in.lab_out, N * 24, hipMemcpyDeviceToHost, ctx->out_stream));
+        for (int i = 0; i < kStatsOutputs; ++i)
+            if (stage_of[i] == stage && host_out[i] && !stats_small_output(out_sizes[i]))
+                ok(hipMemcpyAsync(host_out[i], od[i], out_sizes[i], hipMemcpyDeviceToHost, ctx->out_stream));
+        if (stage != 2) return;
+        // the small outputs lie next to each other at the start of the staging buffer: one copy for all of them
+        for (int i = 0; i < kStatsOutputs; ++i) {
+            if (!stats_small_output(out_sizes[i])) continue;
+            if (!small_base || od[i] < small_base) small_base = od[i];
+        }
+        for (int i = 0; i < kStatsOutputs; ++i)
+            if (stats_small_output(out_sizes[i])) small_hi = std::max(small_hi, (size_t)(od[i] - small_base) + out_sizes[i]);
+        if (small_base && ok(ctx->stats_small_host.ensure(small_hi)))
+            ok(hipMemcpyAsync(ctx->stats_small_host.p, small_base + small_lo, small_hi - small_lo, hipMemcpyDeviceToHost, ctx->out_stream));
+    };
+    if (surface_stats_core(ctx, who, 1, &S, T, in, none, od, out_sizes, hook)) {
+        (void)hipStreamSynchronize(ctx->in_stream);        // nothing of this call stays in flight from or towards the caller's arrays
+        (void)hipStreamSynchronize(ctx->out_stream);
+        return -1;
+    }
+    if (hook_error != hipSuccess) return ctx->fail(hook_error, "statistics downloads");
+    FS_HIP(hipStreamSynchronize(ctx->out_stream));
     for (int i = 0; i < kStatsOutputs; ++i)
-        if (host_out[i]) FS_HIP(hipMemcpyAsync(host_out[i], od[i], out_sizes[i], hipMemcpyDeviceToHost, ctx->stream));
-    if (in.lab_out) FS_HIP(hipMemcpyAsync(lab_out, in.lab_out, N * 24, hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(hipStreamSynchronize(ctx->stream));
+        if (host_out[i] && stats_small_output(out_sizes[i]))
+            std::memcpy(host_out[i], ctx->stats_small_host.as<char>() + (od[i] - small_base), out_sizes[i]);
     return 0;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -155,8 +156,13 @@ struct StatsScratchSizes { size_t zero, ones, ext, plain; };
 StatsScratchSizes stats_scratch_sizes(int S, int T, int nblk);
 void stats_carve_scratch(StatsFrame &f, int T, int nblk, char *zero, char *ones, char *ext, char *plain);
 int stats_blocks_per_frame(int H, int W);
+// after_stage (may be empty) is called when the kernels that complete a group of outputs have been enqueued:
+// 0 = lab_work; 1 = offsets, patch_points, avg_pos, counts, centroids, centroid_idx, surfaces_out; 2 = everything;
+// and before the first kernel that reads a group of inputs: 10 = rgb, 11 = surfaces and patches, 12 = points_3d,
+// 13 = edges, angles, lab (when it is an input), texture
+using StatsStageHook = std::function<void(int)>;
 hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame *frames_host, int n, const StatsBatchWork &w, int H, int W,
-                                      int T, hipStream_t st);
+                                      int T, hipStream_t st, const StatsStageHook &after_stage = StatsStageHook());
 // pairwise reductions (k_pairs.hip); device pointers.  pooled: S * PA * PB floats of scratch, out [S][S]
 void launch_chi_squared(const double *hist, float *pooled, float *out, int A, int B, int S, int ph, int pw, int sh, int sw,
                         hipStream_t st);

@@ -544,7 +544,7 @@ int stats_blocks_per_frame(int H, int W) { return (H * W + SPB - 1) / SPB; }
 // count: [n][H*W] int32 work arrays; lin: 256 linearised sRGB channel values (used when a frame gives rgb instead of lab);
 // ext_all / ext_words: the batch's extent region; err: one int, cleared by the caller.
 hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame *frames_host, int n, const StatsBatchWork &w, int H, int W,
-                                      int T, hipStream_t st)
+                                      int T, hipStream_t st, const StatsStageHook &after_stage)
 {
     const int N = H * W;
     const int nblk = stats_blocks_per_frame(H, W);
@@ -557,15 +557,21 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     }
     const dim3 by_pixel((N + SB - 1) / SB, n), by_block(nblk, n);
     hipLaunchKernelGGL(stats_fill_kernel, dim3((unsigned)((w.ext_words + SB - 1) / SB)), dim3(SB), 0, st, w.ext_all, w.ext_words, ~0u, 0u);
+    if (any_rgb && after_stage) after_stage(10);
     if (any_rgb) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N);
+    if (any_rgb && after_stage) after_stage(0);
+    if (after_stage) after_stage(11);
     hipLaunchKernelGGL(stats_prepare_kernel, by_block, dim3(SB), 4 * Smax * sizeof(uint32_t), st, frames, w.surf32, w.pat32, w.err, H, W);
     hipLaunchKernelGGL(stats_offsets_kernel, dim3(n), dim3(1024), 0, st, frames, nblk);
     hipLaunchKernelGGL(stats_points_kernel, by_block, dim3(SB), 16 * Smax * sizeof(uint32_t), st, frames, w.pat32, N, W);
     hipLaunchKernelGGL(stats_centroid_kernel<1>, by_block, dim3(SB), Smax * sizeof(unsigned long long), st, frames, w.pat32, N, W);
     hipLaunchKernelGGL(stats_centroid_kernel<2>, by_block, dim3(SB), Smax * sizeof(unsigned long long), st, frames, w.pat32, N, W);
+    if (after_stage) after_stage(12);
     hipLaunchKernelGGL(stats_centroid_finish_kernel, dim3((Smax + SB - 1) / SB, n), dim3(SB), 0, st, frames, W);
     launch_label_components(w.surf32, w.parent, w.count, n, H, W, st);
     hipLaunchKernelGGL(stats_keep_kernel, by_pixel, dim3(SB), 0, st, frames, w.surf32, w.parent, N);
+    if (after_stage) after_stage(1);
+    if (after_stage) after_stage(13);
     hipLaunchKernelGGL(stats_accumulate_kernel, by_block, dim3(SB), 10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double), st, frames,
                        w.surf32, w.pat32, w.err, H, W);
     if (any_texture)
@@ -573,6 +579,7 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     const size_t n_fin = std::max<size_t>((size_t)256 * 256 * Smax, (size_t)Smax * T);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((n_fin + SB - 1) / SB), n), dim3(SB), 0, st, frames, T);
     hipLaunchKernelGGL(stats_neighbors_kernel, dim3((unsigned)(((size_t)Smax * Smax + SB - 1) / SB), n), dim3(SB), 0, st, frames);
+    if (after_stage) after_stage(2);
     return hipGetLastError();
 }
 
