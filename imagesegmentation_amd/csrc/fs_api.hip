@@ -139,6 +139,41 @@ bool host_memory_is_page_locked(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
+// Sources of a call's uploads: arrays in pageable memory are copied into the context's page-locked staging block first
+// (the runtime's own path for pageable sources holds the calling thread several times longer than that memcpy).
+// want() every source, then begin(), then from() in the same order.  The entry points that use it end with the stream
+// drained, so the block is free again when the next call begins.
+class StagedSources {
+  public:
+    StagedSources(fs_ctx *c, HostBuf &b) : ctx_(c), buf_(b) {}
+    void want(const void *src, size_t bytes)
+    {
+        if (bytes && !host_memory_is_page_locked(src)) total_ += (bytes + 255) / 256 * 256;
+    }
+    hipError_t begin() { return buf_.ensure(total_); }
+    const void *from(const void *src, size_t bytes)
+    {
+        if (!bytes || host_memory_is_page_locked(src)) return src;
+        char *dst = buf_.as<char>() + used_;
+        std::memcpy(dst, src, bytes);
+        used_ += (bytes + 255) / 256 * 256;
+        return dst;
+    }
+    // room for `bytes` that the caller fills in itself (declare it with want_block() before begin())
+    void want_block(size_t bytes) { total_ += (bytes + 255) / 256 * 256; }
+    void *block(size_t bytes)
+    {
+        char *dst = buf_.as<char>() + used_;
+        used_ += (bytes + 255) / 256 * 256;
+        return dst;
+    }
+
+  private:
+    fs_ctx *ctx_;
+    HostBuf &buf_;
+    size_t total_ = 0, used_ = 0;
+};
+
 int set_device(fs_ctx *ctx)
 {
     FS_HIP(hipSetDevice(ctx->device));
@@ -1152,8 +1187,17 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     if (!ctx->have_params) return ctx->fail("fs_apply_crf: call fs_set_gauss_params first");
     if (!labels || !depth || !rgb || !angles || !out) return ctx->fail("fs_apply_crf: null argument");
     const size_t N = ctx->N(), px = (size_t)n * N;
-    // int64 labels -> int32 on the host (tiny), maximum per frame gives the channel count
-    std::vector<int32_t> lab32(px);
+    StagedSources up(ctx, ctx->stats_in_host);
+    up.want_block(px * 4);
+    const bool out_locked = host_memory_is_page_locked(out);
+    if (!out_locked) up.want_block(px * 8);                 // a pageable result array is filled from page-locked memory as well
+    up.want(depth, px * 2);
+    up.want(rgb, px * 3);
+    up.want(angles, px * 8);
+    FS_HIP(up.begin());
+    // int64 labels -> int32 on the host (into page-locked memory), maximum per frame gives the channel count
+    int32_t *lab32 = static_cast<int32_t *>(up.block(px * 4));
+    int64_t *out_stage = out_locked ? out : static_cast<int64_t *>(up.block(px * 8));
     std::vector<int> S(n);
     for (int i = 0; i < n; ++i) {
         int64_t mx = 0;
@@ -1168,10 +1212,10 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     }
     FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
     FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
-    FS_HIP(hipMemcpyAsync(ctx->depth16.p, depth, px * 2, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, px * 3, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(hipMemcpyAsync(ctx->angles.p, angles, px * 8, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32.data(), px * 4, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->depth16.p, up.from(depth, px * 2), px * 2, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, up.from(rgb, px * 3), px * 3, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->angles.p, up.from(angles, px * 8), px * 8, hipMemcpyHostToDevice, ctx->stream));
     int32_t *maxa = ctx->counts.as<int32_t>() + n;
     FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
     if (const int th = crf_fused_tile_height(ctx->r))
@@ -1182,8 +1226,9 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     if (run_crf_batch(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), ctx->angles.as<float>(), ctx->patches32.as<int32_t>(),
                       S.data(), ma.data(), 1, ctx->surfaces64.as<int64_t>()))
         return -1;
-    FS_HIP(hipMemcpyAsync(out, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipMemcpyAsync(out_stage, ctx->surfaces64.p, px * 8, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
+    if (!out_locked) std::memcpy(out, out_stage, px * 8);
     return 0;
 }
 
@@ -1542,7 +1587,10 @@ int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int 
     FS_HIP(ctx->st_in.ensure(in_bytes));
     FS_HIP(ctx->st_scratch.ensure(pooled_bytes));
     FS_HIP(ctx->st_out.ensure(out_bytes));
-    FS_HIP(hipMemcpyAsync(ctx->st_in.p, hist, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    StagedSources up(ctx, ctx->stats_in_host);
+    up.want(hist, in_bytes);
+    FS_HIP(up.begin());
+    FS_HIP(hipMemcpyAsync(ctx->st_in.p, up.from(hist, in_bytes), in_bytes, hipMemcpyHostToDevice, ctx->stream));
     launch_chi_squared(ctx->st_in.as<double>(), ctx->st_scratch.as<float>(), ctx->st_out.as<float>(), A, B, S, pool_h, pool_w, stride_h,
                        stride_w, ctx->stream);
     FS_HIP(hipGetLastError());
@@ -1581,8 +1629,12 @@ int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *det
     int64_t *d_a = ctx->st_in.as<int64_t>(), *d_o = d_a + N;
     unsigned *d_ov = ctx->st_out.as<unsigned>();
     int *d_err = reinterpret_cast<int *>(d_ov + cells);
-    FS_HIP(hipMemcpyAsync(d_a, annotation, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(hipMemcpyAsync(d_o, detected, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    StagedSources up(ctx, ctx->stats_in_host);
+    up.want(annotation, N * 8);
+    up.want(detected, N * 8);
+    FS_HIP(up.begin());
+    FS_HIP(hipMemcpyAsync(d_a, up.from(annotation, N * 8), N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(d_o, up.from(detected, N * 8), N * 8, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemsetAsync(d_ov, 0, cells * 4 + 8, ctx->stream));
     launch_overlap_counts(d_a, d_o, d_ov, d_err, (int)N, num_detections, num_annotations, ctx->stream);
     FS_HIP(hipGetLastError());
