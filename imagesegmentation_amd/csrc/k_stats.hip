@@ -138,11 +138,26 @@ __global__ __launch_bounds__(1024) void stats_offsets_kernel(const StatsFrame *_
         counts[t] = c;
         avg_pos[2 * t] = c > 0 ? (double)acc[S + t] / c : 0.0;
         avg_pos[2 * t + 1] = c > 0 ? (double)acc[2 * S + t] / c : 0.0;
-        uint32_t run = (uint32_t)(part[t] - v);
-        for (int b = 0; b < nblk; ++b) {
-            const uint32_t c0 = f.blockcnt[(size_t)b * S + t];
-            f.blockcnt[(size_t)b * S + t] = run;
-            run += c0;
+    }
+    // exclusive scan of every label's block counts, starting at the label's offset: a wave per label, 64 blocks per step
+    // (one lane per label walked the frame's few hundred blocks one dependent load at a time: 50 us for one frame)
+    __shared__ int base[1024];
+    base[t] = part[t] - v;
+    __syncthreads();
+    const int lane = t & 63;
+    for (int l = t >> 6; l < S; l += 1024 / 64) {
+        uint32_t run = (uint32_t)base[l];
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int b = b0 + lane;
+            const uint32_t c0 = b < nblk ? f.blockcnt[(size_t)b * S + l] : 0u;
+            uint32_t x = c0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off);
+                if (lane >= off) x += y;
+            }
+            if (b < nblk) f.blockcnt[(size_t)b * S + l] = run + x - c0;
+            run += __shfl(x, 63);
         }
     }
 }
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(SB) void stats_keep_kernel(const StatsFrame *__rest
 
 // histograms, angle sums, neighbour counts and border sums, norm and per-label extents
 __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ surf32_all,
-                                                              const int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W)
+                                                              const int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W,
+                                                              int pixels_per_block)
 {
     const StatsFrame &f = frames[blockIdx.y];
     const int S = f.S;
@@ -304,8 +320,8 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
     for (int i = threadIdx.x; i < 8 * S; i += SB) she[i] = (i & 1) ? 0u : ~0u;
     for (int i = threadIdx.x; i < 2 * S; i += SB) { s_cnt[i] = 0u; s_ang[i] = 0.0; }
     __syncthreads();
-    for (int k = 0; k < SPB / SB; ++k) {
-        const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
+    for (int k = 0; k < pixels_per_block / SB; ++k) {
+        const int p = blockIdx.x * pixels_per_block + k * SB + threadIdx.x;
         const bool in = p < N;
         const int y = in ? p / W : 0, x = in ? p - y * W : 0;
         const int s = in ? surf32[p] : 0;
@@ -572,8 +588,12 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     hipLaunchKernelGGL(stats_keep_kernel, by_pixel, dim3(SB), 0, st, frames, w.surf32, w.parent, N);
     if (after_stage) after_stage(1);
     if (after_stage) after_stage(13);
-    hipLaunchKernelGGL(stats_accumulate_kernel, by_block, dim3(SB), 10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double), st, frames,
-                       w.surf32, w.pat32, w.err, H, W);
+    // a few frames cannot fill the chip with 1 024-pixel blocks, and a block's pixels go through one after the other,
+    // each a chain of loads and atomics: one pixel per lane then (more blocks flush their per-label sums, which a
+    // large batch would pay for)
+    const int acc_ppb = (size_t)n * nblk < 2048 ? SB : SPB;
+    hipLaunchKernelGGL(stats_accumulate_kernel, dim3((N + acc_ppb - 1) / acc_ppb, n), dim3(SB),
+                       10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double), st, frames, w.surf32, w.pat32, w.err, H, W, acc_ppb);
     if (any_texture)
         hipLaunchKernelGGL(stats_texture_kernel, dim3(H / 4, n), dim3(SB), 0, st, frames, w.surf32, w.pat32, N, W, W / 4, T);
     const size_t n_fin = std::max<size_t>((size_t)256 * 256 * Smax, (size_t)Smax * T);
