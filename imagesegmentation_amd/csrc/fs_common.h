@@ -113,7 +113,7 @@ size_t cc_blocks_per_image(int H, int W);
 void launch_connected_components(const uint8_t *mask, const CcWork &w, int min_size_exclusive, int64_t *labels64,
                                  int32_t *labels32, int n, int H, int W, hipStream_t st);
 // components of a label image (equal non-zero values, 4-connectivity): parent[p] = flat index of the first
-// pixel of p's component (-1 where the label is 0), count[root] = pixels of the component
+// pixel of p's component (-1 where the label is 0), count[root] = pixels of the component (count may be null: not wanted)
 void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *count, int n, int H, int W, hipStream_t st);
 // per-surface statistics (k_stats.hip): one descriptor per frame of a batch; every pointer is device memory
 struct StatsFrame {

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LTW * LTH) void cc_local_kernel(const T *__restrict
     const int rl = m ? lds_find(lab, l) : -1;
     if (in) {
         parent[fo + (size_t)y * W + x] = m ? (y0 + rl / LTW) * W + x0 + (rl & (LTW - 1)) : -1;
-        if (!SIZES) count[fo + (size_t)y * W + x] = 0;
+        if (!SIZES && count) count[fo + (size_t)y * W + x] = 0;
     }
     if (SIZES) {
         // sizes of the tile-local components: one LDS add per distinct root of a wave (a row holds few)
@@ -213,6 +213,19 @@ __global__ __launch_bounds__(CC_BLOCK) void cc_sum_sizes_kernel(int32_t *__restr
     while (q != a) { a = q; q = ld_parent(parent + fo, a); }
     if (a != p) parent[fo + p] = a;
     atomicAdd(count + fo + a, ls);
+}
+
+// every pixel points at its component's root afterwards (no sizes: for callers that only compare roots)
+__global__ __launch_bounds__(CC_BLOCK) void cc_flatten_kernel(int32_t *__restrict__ parent, int N)
+{
+    const size_t fo = (size_t)blockIdx.y * N;
+    const int p = blockIdx.x * CC_BLOCK + threadIdx.x;
+    if (p >= N) return;
+    const int par = parent[fo + p];
+    if (par < 0) return;
+    int a = par, q = parent[fo + a];
+    while (q != a) { a = q; q = parent[fo + a]; }
+    if (a != par) parent[fo + p] = a;           // (writes only shorten paths: concurrent readers still reach the root)
 }
 
 __global__ __launch_bounds__(CC_BLOCK) void cc_flatten_count_kernel(int32_t *__restrict__ parent, int32_t *__restrict__ count, int N)
@@ -531,7 +544,8 @@ void launch_label_components(const int32_t *labels, int32_t *parent, int32_t *co
     const int N = H * W;
     const dim3 grid((unsigned)cc_blocks_per_image(H, W), n), block(CC_BLOCK);
     launch_local_and_border<int32_t, false>(labels, parent, count, nullptr, n, H, W, st);
-    hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, parent, count, N);
+    if (count) hipLaunchKernelGGL(cc_flatten_count_kernel, grid, block, 0, st, parent, count, N);
+    else hipLaunchKernelGGL(cc_flatten_kernel, grid, block, 0, st, parent, N);
 }
 
 }  // namespace fs

@@ -584,7 +584,7 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     hipLaunchKernelGGL(stats_centroid_kernel<2>, by_block, dim3(SB), Smax * sizeof(unsigned long long), st, frames, w.pat32, N, W);
     if (after_stage) after_stage(12);
     hipLaunchKernelGGL(stats_centroid_finish_kernel, dim3((Smax + SB - 1) / SB, n), dim3(SB), 0, st, frames, W);
-    launch_label_components(w.surf32, w.parent, w.count, n, H, W, st);
+    launch_label_components(w.surf32, w.parent, nullptr, n, H, W, st);      // the keep pass compares roots; sizes are not needed
     hipLaunchKernelGGL(stats_keep_kernel, by_pixel, dim3(SB), 0, st, frames, w.surf32, w.parent, N);
     if (after_stage) after_stage(1);
     if (after_stage) after_stage(13);
