@@ -68,6 +68,8 @@ struct fs_ctx {
     DevBuf publish_seq;                            // device word: one-frame calls so far (the kernels count)
     unsigned publish_expected = 0;                 // ... as the host counts them
     DevBuf spec_descs;
+    DevBuf apply_stats;                            // fs_apply_crf: per-frame label maxima and flags
+    HostBuf apply_stats_host;
     HostBuf spec_descs_host;
     std::vector<CrfFrameDesc> spec_shadow;         // what spec_descs holds
     int spec_cap = 0;                              // label channels the Q planes held when the last such launch went out
@@ -660,7 +662,7 @@ void fs_destroy(fs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->spec_descs, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
+    DevBuf *bufs[] = {&ctx->spec_descs, &ctx->apply_stats, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin, &ctx->st_lab,
@@ -685,6 +687,7 @@ void fs_destroy(fs_ctx *ctx)
     ctx->spec_descs_host.release();
     ctx->publish_host.release();
     ctx->stats_small_host.release();
+    ctx->apply_stats_host.release();
     ctx->stats_in_host.release();
     ctx->frames_in_host.release();
     ctx->descs_host.release();
@@ -1188,41 +1191,39 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     if (!labels || !depth || !rgb || !angles || !out) return ctx->fail("fs_apply_crf: null argument");
     const size_t N = ctx->N(), px = (size_t)n * N;
     StagedSources up(ctx, ctx->stats_in_host);
-    up.want_block(px * 4);
     const bool out_locked = host_memory_is_page_locked(out);
     if (!out_locked) up.want_block(px * 8);                 // a pageable result array is filled from page-locked memory as well
+    up.want(labels, px * 8);
     up.want(depth, px * 2);
     up.want(rgb, px * 3);
     up.want(angles, px * 8);
     FS_HIP(up.begin());
-    // int64 labels -> int32 on the host (into page-locked memory), maximum per frame gives the channel count
-    int32_t *lab32 = static_cast<int32_t *>(up.block(px * 4));
     int64_t *out_stage = out_locked ? out : static_cast<int64_t *>(up.block(px * 8));
-    std::vector<int> S(n);
-    for (int i = 0; i < n; ++i) {
-        int64_t mx = 0;
-        for (size_t k = 0; k < N; ++k) {
-            const int64_t v = labels[i * N + k];
-            if (v < 0 || v > kMaxLabels - 2)
-                return ctx->fail("fs_apply_crf: label " + std::to_string(v) + " outside [0, " + std::to_string(kMaxLabels - 2) + "]");
-            lab32[i * N + k] = (int32_t)v;
-            if (v > mx) mx = v;
-        }
-        S[i] = (int)mx + 2;   // val = max + 1 surfaces, + the "unassigned" channel (post_processing.py:10-11)
-    }
     FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
     FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
-    FS_HIP(hipMemcpyAsync(ctx->patches32.p, lab32, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the int64 labels go up as they are (surfaces64 holds them until it receives the result) and are narrowed,
+    // range-checked and maximised on the device: the counts come back with the tile scan's in one read-back
+    FS_HIP(hipMemcpyAsync(ctx->surfaces64.p, up.from(labels, px * 8), px * 8, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemcpyAsync(ctx->depth16.p, up.from(depth, px * 2), px * 2, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemcpyAsync(ctx->rgb8.p, up.from(rgb, px * 3), px * 3, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(hipMemcpyAsync(ctx->angles.p, up.from(angles, px * 8), px * 8, hipMemcpyHostToDevice, ctx->stream));
-    int32_t *maxa = ctx->counts.as<int32_t>() + n;
-    FS_HIP(hipMemsetAsync(maxa, 0, n * sizeof(int32_t), ctx->stream));
+    FS_HIP(ctx->apply_stats.ensure(3 * (size_t)ctx->max_batch * sizeof(int32_t)));
+    FS_HIP(ctx->apply_stats_host.ensure(3 * (size_t)ctx->max_batch * sizeof(int32_t)));
+    int32_t *d_stats = ctx->apply_stats.as<int32_t>();      // [n] largest label | [n] out of range | [n] most listed labels of a tile
+    int32_t *maxa = d_stats + 2 * n;
+    FS_HIP(hipMemsetAsync(d_stats, 0, 3 * n * sizeof(int32_t), ctx->stream));
+    launch_crf_labels_to_int32(ctx->surfaces64.as<int64_t>(), ctx->patches32.as<int32_t>(), d_stats, n, (int)N, kMaxLabels - 2, ctx->stream);
     if (const int th = crf_fused_tile_height(ctx->r))
         launch_crf_tile_active(ctx->patches32.as<int32_t>(), n, ctx->H, ctx->W, 32, th, ctx->r, ctx->tile_recs.as<int32_t>(), maxa, ctx->stream);
-    FS_HIP(hipMemcpyAsync(ctx->counts_host.as<int32_t>() + n, maxa, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->apply_stats_host.p, d_stats, 3 * n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int> ma(ctx->counts_host.as<int32_t>() + n, ctx->counts_host.as<int32_t>() + 2 * n);
+    const int32_t *hs = ctx->apply_stats_host.as<int32_t>();
+    std::vector<int> S(n), ma(n);
+    for (int i = 0; i < n; ++i) {
+        if (hs[n + i]) return ctx->fail("fs_apply_crf: a label of frame " + std::to_string(i) + " lies outside [0, " + std::to_string(kMaxLabels - 2) + "]");
+        S[i] = hs[i] + 2;     // val = max + 1 surfaces, + the "unassigned" channel (post_processing.py:10-11)
+        ma[i] = hs[2 * n + i];
+    }
     if (run_crf_batch(ctx, n, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), ctx->angles.as<float>(), ctx->patches32.as<int32_t>(),
                       S.data(), ma.data(), 1, ctx->surfaces64.as<int64_t>()))
         return -1;

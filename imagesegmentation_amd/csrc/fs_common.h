@@ -223,6 +223,9 @@ void launch_planes_to_rows(const float *planes, float *rows, size_t P, int S, hi
 // clear (may be null): clear_words words zeroed on the way (the tile queues of the updates that follow)
 void launch_crf_tile_active(const int32_t *patches, int n, int H, int W, int tile_w, int tile_h, int grow, int32_t *recs,
                             int32_t *max_active, hipStream_t st, unsigned *clear = nullptr, int clear_words = 0);
+// int64 label images [n][N] -> int32; stats[n] (zeroed) receives every frame's largest label, stats[n + frame] = 1 if a label
+// of the frame lies outside [0, max_label] (device pointers)
+void launch_crf_labels_to_int32(const int64_t *labels, int32_t *out, int32_t *stats, int n, int N, int max_label, hipStream_t st);
 // number of listed labels of `total` consecutive tile records -> out[total] (device pointers)
 void launch_crf_tile_counts(const int32_t *recs, int32_t *out, int total, hipStream_t st);
 // mode bits for launch_crf_iter

@@ -613,6 +613,36 @@ __global__ __launch_bounds__(256) void crf_pack_features_kernel(const uint16_t *
     }
 }
 
+// int64 label images -> int32 working copies; stats[frame] = largest label of the frame, stats[nframes + frame] = 1 if
+// a label lies outside [0, max_label] (such pixels become 0).  stats must be zeroed.
+__global__ __launch_bounds__(256) void crf_labels_to_int32_kernel(const int64_t *__restrict__ labels, int32_t *__restrict__ out,
+                                                                  int32_t *__restrict__ stats, int N, int nframes, int max_label)
+{
+    __shared__ int s_max, s_bad;
+    if (threadIdx.x == 0) { s_max = 0; s_bad = 0; }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+    int v = 0;
+    bool bad = false;
+    if (p < N) {
+        const int64_t l = labels[(size_t)frame * N + p];
+        bad = l < 0 || l > max_label;
+        v = bad ? 0 : (int)l;
+        out[(size_t)frame * N + p] = v;
+    }
+    // one LDS atomic per wave, one global atomic per block
+    int m = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&s_max, m);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_max > 0) atomicMax(stats + frame, s_max);
+        if (s_bad) stats[nframes + frame] = 1;
+    }
+}
+
 template <int R, int PY, int NCH>
 hipError_t launch_iter_t(const CrfFrameDesc *descs, int nframes, const CrfGeom &g, float weight, float evidence, int last, hipStream_t st)
 {
@@ -718,6 +748,11 @@ static double fused_c3(const CrfParams &P) { return 4.0 * P.t33 * 1.442695040888
 
 float crf_angle_feature_scale(const CrfParams &P) { return P.mode == 0 ? (float)std::sqrt(fused_c3(P)) : 1.0f; }
 float crf_colour_feature_scale(const CrfParams &P) { return P.mode == 0 ? (float)std::sqrt(fused_c2(P)) : 1.0f; }
+
+void launch_crf_labels_to_int32(const int64_t *labels, int32_t *out, int32_t *stats, int n, int N, int max_label, hipStream_t st)
+{
+    hipLaunchKernelGGL(crf_labels_to_int32_kernel, dim3((N + 255) / 256, n), dim3(256), 0, st, labels, out, stats, N, n, max_label);
+}
 
 void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const float *angles, void *featA, void *featB,
                               size_t total, const CrfParams &P, hipStream_t st)
