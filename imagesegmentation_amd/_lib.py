@@ -534,6 +534,6 @@ class Context:
         c, _ = self._batch(rgb, (3,))
         a, _ = self._batch(angles, (2,))
         lab, d, c, a = _arr(lab, np.int64), _arr(d, np.uint16), _arr(c, np.uint8), _arr(a, np.float32)
-        out = np.empty_like(lab)
+        out = pinned_empty(lab.shape, np.int64)          # page-locked: the download is a DMA transfer into the result itself
         self._check(self._lib.fs_apply_crf(self._h, lab.shape[0], _ptr(lab), _ptr(d), _ptr(c), _ptr(a), _ptr(out)))
         return out[0] if single else out

@@ -107,6 +107,24 @@ def test_apply_crf_matches_oracle(oracle):
     assert pp.get_postprocessing_model(do_post_processing=False)(data) is data
 
 
+def test_apply_crf_rejects_labels_out_of_range_and_recovers():
+    """Labels are narrowed and range-checked on the device: a label beyond the channel limit or a negative one fails
+    the call with a message, and the same context then processes a valid segmentation."""
+    from imagesegmentation_amd._lib import Context
+    g = np.load(os.path.join(GOLD, "synth_13.npz"))
+    depth, rgb, angles = g["depth"], g["rgb"], g["angles"]
+    final = g["surfaces"].astype(np.int64)
+    H, W = final.shape
+    with Context(H, W, max_batch=1) as ctx:
+        good = ctx.apply_crf(final, depth, rgb, angles)
+        for bad_value in (511, -1, 2 ** 40):
+            bad = final.copy()
+            bad[H // 2, W // 2] = bad_value
+            with pytest.raises(RuntimeError, match="outside"):
+                ctx.apply_crf(bad, depth, rgb, angles)
+        assert np.array_equal(ctx.apply_crf(final, depth, rgb, angles), good)
+
+
 @pytest.mark.parametrize("r", [3, 10, 15])
 def test_other_window_radii(oracle, r):
     from imagesegmentation_amd._lib import Context
