@@ -108,3 +108,41 @@ def test_one_frame_calls_on_the_default_stream():
             ctx.use_own_stream()
     finally:
         dev.free()
+
+
+def test_two_contexts_in_two_threads():
+    """One context per thread on the same GPU, both at work at once (ctypes releases the interpreter lock during the
+    calls): one-frame calls with their polled label counts and batched calls, each thread's results those of a run
+    alone."""
+    import threading
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = 192, 256
+    sets = [make_batch([51, 52, 53, 54], H, W), make_batch([61, 62, 63, 64], H, W)]
+    with Context(H, W, max_batch=4) as ctx:
+        alone = [ctx.find_surfaces_batch(d, c) for d, c in sets]
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            d, c = sets[k]
+            with Context(H, W, max_batch=4) as own:
+                singles = [own.find_surfaces_batch(d[i], c[i]) for i in range(4) for _ in range(3)]
+                batch = own.find_surfaces_batch(d, c)
+                results[k] = (singles, batch, own.speculation_counts())
+        except Exception as e:                      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for k in range(2):
+        singles, batch, (held, repeated) = results[k]
+        assert held == 12 and repeated == 0
+        for key in KEYS:
+            assert np.array_equal(batch[key], alone[k][key]), key
+            for j, one in enumerate(singles):
+                assert np.array_equal(one[key], alone[k][key][j // 3]), (key, j)
