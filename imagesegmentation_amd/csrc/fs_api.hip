@@ -1302,7 +1302,6 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
             FS_HIP(ctx->st_lin.ensure(sizeof(lin)));
             FS_HIP(hipMemcpy(ctx->st_lin.p, lin, sizeof(lin), hipMemcpyHostToDevice));
         }
-        if (!in.lab_out) FS_HIP(ctx->st_lab.ensure((size_t)n * N * 24));
     }
     char *p = ctx->st_out.as<char>();
     int *d_err = reinterpret_cast<int *>(p);
@@ -1330,7 +1329,10 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
     FS_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
     std::vector<StatsFrame> &fh = ctx->st_descs_host;
     fh.assign(n, StatsFrame{});
-    double *lab_work = in.rgb ? (in.lab_out ? in.lab_out : ctx->st_lab.as<double>()) : nullptr;
+    // colours given as rgb: the conversion writes the Lab image where the caller wants it, or, when nobody wants it, only the
+    // pixels' histogram bins (into the work array the component pass no longer uses for sizes)
+    double *lab_work = in.rgb ? in.lab_out : nullptr;
+    uint32_t *color_bins = in.rgb && !in.lab_out ? reinterpret_cast<uint32_t *>(w.count) : nullptr;
     for (int i = 0; i < n; ++i) {
         StatsFrame &f = fh[i];
         f.S = S[i];
@@ -1341,6 +1343,7 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
         f.angles = in.angles + (size_t)i * N * 2;
         f.rgb = in.rgb ? in.rgb + (size_t)i * N * 3 : nullptr;
         f.lab_work = lab_work ? lab_work + (size_t)i * N * 3 : nullptr;
+        f.color_bin = color_bins ? color_bins + (size_t)i * N : nullptr;
         f.lab = in.rgb ? f.lab_work : in.lab + (size_t)i * N * 3;
         f.texture = in.texture ? in.texture + (size_t)i * (N / 16) * T : nullptr;
         stats_carve_scratch(f, T, nblk, zero, ones, ext, plain);

@@ -123,7 +123,9 @@ struct StatsFrame {
     const float *points_3d, *angles;     // [H][W][3], [H][W][2]
     const double *lab;                   // [H][W][3]: the caller's, or lab_work when rgb is given
     const uint8_t *rgb;                  // [H][W][3] or null
-    double *lab_work;                    // where the colour conversion writes (rgb != null)
+    double *lab_work;                    // where the colour conversion writes (rgb != null), or null: only color_bin is wanted
+    uint32_t *color_bin;                 // [H][W] colour-histogram bin (a << 8 | b) of every pixel, written by the colour conversion
+                                         // when nobody asked for the Lab image itself (lab_work == null); else null
     const float *texture;                // [H/4][W/4][T] or null
     // label-indexed scratch (stats_carve_scratch)
     unsigned long long *acc, *best, *nb_sum;

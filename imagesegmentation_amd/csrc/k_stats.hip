@@ -54,7 +54,10 @@ __device__ __forceinline__ void wave_histogram_add(uint32_t *__restrict__ hist, 
 
 // CIE L*a*b* of an sRGB pixel (D65, 2-degree observer): the definition utils.rgb_to_Lab restates for
 // skimage.color.rgb2lab (utils.py:7-8 of the reference).  lin[v] = linearised channel value of byte v.
-__global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin, int N)
+// When the Lab image itself is not an output, only what the colour histogram needs of it leaves the kernel: the
+// pixel's bin round(a + 127) << 8 | round(b + 127) (process_surfaces.py:265-267), 4 bytes instead of 24 written and 16 read.
+__global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin, int N,
+                                                       int *__restrict__ err)
 {
     const StatsFrame &f = frames[blockIdx.y];
     const int p = blockIdx.x * SB + threadIdx.x;
@@ -65,10 +68,18 @@ __global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restr
     double t[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) t[c] = xyz[c] > 0.008856 ? cbrt(xyz[c]) : 7.787 * xyz[c] + 16.0 / 116.0;
-    double *o = f.lab_work + 3 * (size_t)p;
-    o[0] = 116.0 * t[1] - 16.0;
-    o[1] = 500.0 * (t[0] - t[1]);
-    o[2] = 200.0 * (t[1] - t[2]);
+    const double a_ = 500.0 * (t[0] - t[1]), b_ = 200.0 * (t[1] - t[2]);
+    if (f.lab_work) {
+        double *o = f.lab_work + 3 * (size_t)p;
+        o[0] = 116.0 * t[1] - 16.0;
+        o[1] = a_;
+        o[2] = b_;
+    } else {
+        const long a = (long)rint(a_ + 127.0), b = (long)rint(b_ + 127.0);
+        const bool ok = a >= 0 && a <= 255 && b >= 0 && b <= 255;
+        f.color_bin[p] = ok ? (uint32_t)(a * 256 + b) : 0xffffffffu;      // (an sRGB colour never leaves the range; the
+        (void)err;                                                        // accumulation pass reports the flag if one does)
+    }
 }
 
 // relabel, int32 working copies, interior counts and position sums, patch-pixel counts per block (the input of
@@ -304,6 +315,7 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
     const int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * H * W, *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * H * W;
     const int32_t *__restrict__ edges = f.edges;
     const double *__restrict__ lab = f.lab;
+    const uint32_t *__restrict__ color_bin_of = f.color_bin;
     const float *__restrict__ angles = f.angles, *__restrict__ points_3d = f.points_3d;
     uint32_t *__restrict__ hist_color = f.hist_color, *__restrict__ hist_angle = f.hist_angle, *__restrict__ cnt = f.cnt;
     uint32_t *__restrict__ nb_count = f.nb_count, *__restrict__ extent = f.extent;
@@ -344,9 +356,15 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
         }
         if (s > 0) {
             // colour histogram, :265-267
-            const long a = (long)rint(lab[3 * (size_t)p + 1] + 127.0), b = (long)rint(lab[3 * (size_t)p + 2] + 127.0);
-            if (a < 0 || a > 255 || b < 0 || b > 255) *err = 2;
-            else { color_on = true; color_bin = (uint32_t)((a * 256 + b) * S + s); }
+            if (color_bin_of) {
+                const uint32_t ab = color_bin_of[p];
+                if (ab == 0xffffffffu) *err = 2;
+                else { color_on = true; color_bin = ab * (uint32_t)S + (uint32_t)s; }
+            } else {
+                const long a = (long)rint(lab[3 * (size_t)p + 1] + 127.0), b = (long)rint(lab[3 * (size_t)p + 2] + 127.0);
+                if (a < 0 || a > 255 || b < 0 || b > 255) *err = 2;
+                else { color_on = true; color_bin = (uint32_t)((a * 256 + b) * S + s); }
+            }
             atomicAdd(&s_cnt[s], 1u);
             // neighbours, :39-55 (pairs with label 0 and pairs of equal labels are zeroed afterwards: skipped)
             if (edges[p] != 0) {
@@ -582,7 +600,7 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     const dim3 by_pixel((N + SB - 1) / SB, n), by_block(nblk, n);
     hipLaunchKernelGGL(stats_fill_kernel, dim3((unsigned)((w.ext_words + SB - 1) / SB)), dim3(SB), 0, st, w.ext_all, w.ext_words, ~0u, 0u);
     if (any_rgb && after_stage) after_stage(10);
-    if (any_rgb) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N);
+    if (any_rgb) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N, w.err);
     if (any_rgb && after_stage) after_stage(0);
     if (after_stage) after_stage(11);
     hipLaunchKernelGGL(stats_prepare_kernel, by_block, dim3(SB), 4 * Smax * sizeof(uint32_t), st, frames, w.surf32, w.pat32, w.err, H, W);
