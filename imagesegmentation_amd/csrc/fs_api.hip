@@ -75,7 +75,7 @@ struct fs_ctx {
     int spec_cap = 0;                              // label channels the Q planes held when the last such launch went out
     int64_t spec_held = 0, spec_repeated = 0;
     // per-surface statistics (one frame in flight)
-    DevBuf st_in, st_work, st_scratch, st_out, st_pool, st_descs, st_lin, st_lab;
+    DevBuf st_in, st_work, st_scratch, st_out, st_pool, st_descs, st_lin;
     std::vector<StatsFrame> st_descs_host;
 
     // timing
@@ -665,7 +665,7 @@ void fs_destroy(fs_ctx *ctx)
     DevBuf *bufs[] = {&ctx->spec_descs, &ctx->apply_stats, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
-                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin, &ctx->st_lab,
+                      &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin,
                       &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
                       &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
     for (DevBuf *b : bufs) b->release();
