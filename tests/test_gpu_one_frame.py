@@ -146,3 +146,32 @@ def test_two_contexts_in_two_threads():
             assert np.array_equal(batch[key], alone[k][key]), key
             for j, one in enumerate(singles):
                 assert np.array_equal(one[key], alone[k][key][j // 3]), (key, j)
+
+
+def test_small_host_calls_with_and_without_early_downloads():
+    """A host-buffer call of one chunk (up to 16 frames) sends each group of outputs to the host as soon as its kernels are
+    enqueued and stages pageable inputs through page-locked memory; the arrays it fills are those of a context that does
+    neither, for pageable and page-locked arrays alike."""
+    from imagesegmentation_amd._lib import Context, pinned_empty
+    from imagesegmentation_amd.synth import make_batch
+    H, W, n = 96, 128, 5
+    d, c = make_batch([71, 72, 73, 74, 75], H, W)
+    old = os.environ.get("FS_NO_EARLY_DOWNLOADS")
+    os.environ["FS_NO_EARLY_DOWNLOADS"] = "1"
+    try:
+        late = Context(H, W, max_batch=n)
+    finally:
+        if old is None:
+            del os.environ["FS_NO_EARLY_DOWNLOADS"]
+        else:
+            os.environ["FS_NO_EARLY_DOWNLOADS"] = old
+    with late, Context(H, W, max_batch=n) as ctx:
+        ref = late.find_surfaces_batch(d, c)
+        pd, pc = pinned_empty(d.shape, np.uint16), pinned_empty(c.shape, np.uint8)
+        pd[...] = d
+        pc[...] = c
+        for depth, rgb, what in ((d, c, "pageable inputs"), (pd, pc, "page-locked inputs"), (pd, c, "one of each")):
+            got = ctx.find_surfaces_batch(depth, rgb)
+            _same(got, ref, what)
+            for i in range(n):
+                _same(ctx.find_surfaces_batch(depth[i], rgb[i]), {k: ref[k][i] for k in KEYS + ("num_surfaces",)}, f"{what}, frame {i}")
