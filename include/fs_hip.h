@@ -130,7 +130,11 @@ int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, 
  * 532) for n frames, mode "Gauss" or "LR" according to the parameters set last: depth uint16 [n][H][W], rgb uint8 [n][H][W][3] ->
  * the arrays of the returned dict / of the out/{index} .npy files (:537-545):
  * angles, vectors, points_3d, patches, depth_edges, surfaces ("Q.npy"),
- * num_surfaces[n] = max(patches)+1.  Any output pointer may be NULL. */
+ * num_surfaces[n] = max(patches)+1.  Any output pointer may be NULL.
+ * Host pointers; returns when every output has arrived.  More than 16 frames go through in chunks of 16 whose
+ * copies run beside the kernels of the neighbouring chunks (page-locked arrays make them DMA transfers:
+ * fs_host_alloc); a call of up to 16 frames sends each group of outputs on its way as soon as the kernels that
+ * complete it are enqueued, and copies inputs that arrive in pageable memory into page-locked memory first. */
 int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint8_t *rgb, float *angles,
                            float *vectors, float *points, int64_t *patches, int32_t *edges, int64_t *surfaces,
                            int32_t *num_surfaces);
@@ -143,8 +147,9 @@ void fs_host_free(void *p);
 
 /* Same with all image arrays resident in device memory (num_surfaces stays a host
  * array).  Work is enqueued on the context's stream; the call returns after the
- * last kernel has been enqueued (it synchronises once internally to read the
- * label counts). */
+ * last kernel has been enqueued (it waits once internally for the label counts: with several frames in
+ * hipStreamSynchronize before the updates are launched, with one frame by polling a page-locked word while
+ * the updates, launched ahead of the counts, already run: fs_get_speculation_counts). */
 int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
                                float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges,
                                int64_t *d_surfaces, int32_t *num_surfaces);
@@ -152,7 +157,8 @@ int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, cons
 /* post_processing.apply_CRF (post_processing.py:4-19): one mean-field pass with
  * `labels` (int64 [n][H][W], e.g. final_surfaces) in the role of the patches, then
  * argmax; depth uint16, rgb uint8, angles float32 [n][H][W][2] as saved by
- * find_surfaces.  Host pointers.  out int64 [n][H][W]. */
+ * find_surfaces.  Host pointers.  out int64 [n][H][W].  Labels must lie in [0, 510] (the frame's channel count is
+ * their maximum + 2); they are checked on the device, and a call that finds one outside fails without touching out. */
 int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *depth, const uint8_t *rgb,
                  const float *angles, int64_t *out);
 
