@@ -1122,7 +1122,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
     };
     // the previous call's kernels may still read the input buffers when the caller drives the stream itself
     FS_HIP(hipStreamSynchronize(ctx->stream));
-    const bool early = chunks == 1 && ctx->early_downloads;
+    const bool early = ctx->early_downloads;
     for (hipEvent_t &e : ctx->early_events)
         if (early && !e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (upload(0)) return -1;
@@ -1131,10 +1131,11 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         if (k + 1 < chunks && upload(k + 1)) return -1;
         FS_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[2 * k], 0));
         const size_t px = cn * N, o = f0 * N;
-        // A call of one chunk has nothing to overlap its downloads with but its own kernels: each group of outputs
-        // starts its way to the host as soon as the kernels that complete it are enqueued (normals, angles and points
-        // after the angle filter, patches and edges after the components), and only the labels wait for the updates.
-        // With several chunks the downloads of a chunk run beside the kernels of the next one anyway.
+        // Each group of a chunk's outputs starts its way to the host as soon as the kernels that complete it are
+        // enqueued (normals, angles and points after the angle filter, patches and edges after the components), and
+        // only the labels wait for the updates: a call of one chunk has nothing else to overlap its downloads with,
+        // and with several chunks the link, which bounds the call, starts on a chunk a CRF's length earlier (111
+        // frames: 35.9 -> 33.5 ms).
         StageHook hook;
         if (early) hook = [&](int stage) -> int {
             FS_HIP(hipEventRecord(ctx->early_events[stage], ctx->stream));
