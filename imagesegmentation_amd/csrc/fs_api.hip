@@ -1125,10 +1125,17 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
     const bool early = ctx->early_downloads;
     for (hipEvent_t &e : ctx->early_events)
         if (early && !e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (upload(0)) return -1;
+    // a call that fails leaves nothing in flight from or towards the caller's arrays
+    auto drained = [&]() {
+        (void)hipStreamSynchronize(ctx->in_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->out_stream);
+        return -1;
+    };
+    if (upload(0)) return drained();
     for (int k = 0; k < chunks; ++k) {
         const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
-        if (k + 1 < chunks && upload(k + 1)) return -1;
+        if (k + 1 < chunks && upload(k + 1)) return drained();
         FS_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[2 * k], 0));
         const size_t px = cn * N, o = f0 * N;
         // Each group of a chunk's outputs starts its way to the host as soon as the kernels that complete it are
@@ -1155,7 +1162,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                               ctx->points.as<float>() + f0 * N * 3, ctx->patches64.as<int64_t>() + f0 * N,
                               ctx->edges.as<int32_t>() + f0 * N, ctx->surfaces64.as<int64_t>() + f0 * N,
                               num_surfaces ? num_surfaces + f0 : nullptr, hook))
-            return -1;
+            return drained();
         FS_HIP(hipEventRecord(ctx->pipe_events[2 * k + 1], ctx->stream));
         FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->pipe_events[2 * k + 1], 0));
         if (!early) {
@@ -1467,7 +1474,7 @@ int surface_stats_host(fs_ctx *ctx, const char *who, int num_surfaces, const int
     hipError_t hook_error = hipSuccess;
     for (hipEvent_t &e : ctx->stats_events)
         if (!e) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    size_t small_lo = 0, small_hi = 0;                      // extent of the small outputs in the staging buffer (device), bytes from od[first]
+    size_t small_hi = 0;                                    // extent of the small outputs in the staging buffer (device), bytes from small_base
     char *small_base = nullptr;
     auto hook = [&](int stage) {
         auto ok = [&](hipError_t e) { if (e != hipSuccess && hook_error == hipSuccess) hook_error = e; return e == hipSuccess; };
@@ -1489,14 +1496,18 @@ int surface_stats_host(fs_ctx *ctx, const char *who, int num_surfaces, const int
         for (int i = 0; i < kStatsOutputs; ++i)
             if (stats_small_output(out_sizes[i])) small_hi = std::max(small_hi, (size_t)(od[i] - small_base) + out_sizes[i]);
         if (small_base && ok(ctx->stats_small_host.ensure(small_hi)))
-            ok(hipMemcpyAsync(ctx->stats_small_host.p, small_base + small_lo, small_hi - small_lo, hipMemcpyDeviceToHost, ctx->out_stream));
+            ok(hipMemcpyAsync(ctx->stats_small_host.p, small_base, small_hi, hipMemcpyDeviceToHost, ctx->out_stream));
     };
     if (surface_stats_core(ctx, who, 1, &S, T, in, none, od, out_sizes, hook)) {
         (void)hipStreamSynchronize(ctx->in_stream);        // nothing of this call stays in flight from or towards the caller's arrays
         (void)hipStreamSynchronize(ctx->out_stream);
         return -1;
     }
-    if (hook_error != hipSuccess) return ctx->fail(hook_error, "statistics downloads");
+    if (hook_error != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->in_stream);
+        (void)hipStreamSynchronize(ctx->out_stream);
+        return ctx->fail(hook_error, "statistics downloads");
+    }
     FS_HIP(hipStreamSynchronize(ctx->out_stream));
     for (int i = 0; i < kStatsOutputs; ++i)
         if (host_out[i] && stats_small_output(out_sizes[i]))
