@@ -551,10 +551,12 @@ __global__ __launch_bounds__(SB) void stats_fill_kernel(uint32_t *__restrict__ a
 StatsScratchSizes stats_scratch_sizes(int S, int T, int nblk)
 {
     StatsScratchSizes z;
-    // acc[4S] u64 | nb_sum[2SS] u64 | angle_sum[2S] f64 | tex_sum[S*T] f64 | hist_color u32 | hist_angle u32 | nb_count[SS] u32 |
-    // cnt[2S] u32 | tex_cnt[S] u32 (+ pad)
+    // hist_color u32 (first: every frame's starts on a 16-byte boundary, which the finalisation's four-bin loads want) |
+    // acc[4S] u64 | nb_sum[2SS] u64 | angle_sum[2S] f64 | tex_sum[S*T] f64 | hist_angle u32 | nb_count[SS] u32 | cnt[2S] u32 |
+    // tex_cnt[S] u32 (+ pad to 16 bytes)
     z.zero = 8 * ((size_t)4 * S + 2 * (size_t)S * S + 2 * S + (size_t)S * T) +
-             4 * (((size_t)256 * 256 * S + 1600 * (size_t)S + (size_t)S * S + 2 * S + S + 1) / 2 * 2);
+             4 * ((size_t)256 * 256 * S + 1600 * (size_t)S + (size_t)S * S + 2 * S + S);
+    z.zero = (z.zero + 15) / 16 * 16;
     z.ones = 8 * (size_t)2 * S;                                   // best[2S] u64
     z.ext = 4 * (size_t)8 * S;                                    // extent[8S] u32
     z.plain = 4 * (((size_t)S + (size_t)nblk * S + 1) / 2 * 2);   // cpix[S] i32 | blockcnt[nblk][S] u32
@@ -565,11 +567,11 @@ void stats_carve_scratch(StatsFrame &f, int T, int nblk, char *zero, char *ones,
 {
     const size_t S = f.S;
     auto take = [](char *&base, size_t bytes) { char *p = base; base += bytes; return p; };
+    f.hist_color = reinterpret_cast<uint32_t *>(take(zero, 4 * (size_t)256 * 256 * S));
     f.acc = reinterpret_cast<unsigned long long *>(take(zero, 8 * 4 * S));
     f.nb_sum = reinterpret_cast<unsigned long long *>(take(zero, 8 * 2 * S * S));
     f.angle_sum = reinterpret_cast<double *>(take(zero, 8 * 2 * S));
     f.tex_sum = reinterpret_cast<double *>(take(zero, 8 * S * T));
-    f.hist_color = reinterpret_cast<uint32_t *>(take(zero, 4 * (size_t)256 * 256 * S));
     f.hist_angle = reinterpret_cast<uint32_t *>(take(zero, 4 * (size_t)1600 * S));
     f.nb_count = reinterpret_cast<uint32_t *>(take(zero, 4 * S * S));
     f.cnt = reinterpret_cast<uint32_t *>(take(zero, 4 * 2 * S));
