@@ -224,10 +224,13 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     // the run of its own XCD and, once that is used up, from the runs of the others (frames differ in cost, so
     // the runs do not end together), until all eight are empty, which every block reaches; the next tile is
     // requested while the current one is worked on.
+    // A block's first tile needs no counter: the first gridDim.x / 8 tiles of every run belong to the blocks whose
+    // index selects that run, one each, and the counters hand out the tiles behind those.
     unsigned qi = blockIdx.x & 7u, queues_left = 8;          // lane 0's cursor over the queues
+    const unsigned dealt = gridDim.x >> 3;                   // (the grid is a multiple of 8 blocks)
     auto next_tile = [&]() -> unsigned {
         while (queues_left) {
-            const unsigned t = atomicAdd(queue + qi * (kCrfQueueStride / sizeof(unsigned)), 1u);
+            const unsigned t = dealt + atomicAdd(queue + qi * (kCrfQueueStride / sizeof(unsigned)), 1u);
             const unsigned id = qi * per_xcd + t;
             if (t < per_xcd && id < tiles_total) return id;
             qi = (qi + 1u) & 7u;
@@ -242,7 +245,10 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     // a small launch claims its next tile only when the window walk is over, in front of the epilogue.
     const bool claim_early = tiles_total > 2u * gridDim.x;
     if (first) publish_counts(descs);
-    if (threadIdx.x == 0) s_ticket = next_tile();
+    if (threadIdx.x == 0) {
+        const unsigned t = blockIdx.x >> 3, id = qi * per_xcd + t;
+        s_ticket = t < per_xcd && id < tiles_total ? id : next_tile();
+    }
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();
   for (;;) {
