@@ -15,6 +15,7 @@ Two ways through the stage exist, with identical results:
     label channels per call (fs_crf_step), so that route stops at 127 surfaces per frame; the fused path carries 512.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -31,7 +32,7 @@ frames_per_call = 37                                 # frames handed to the GPU 
 
 # GPU of this process: FS_DEVICE if set (e.g. several ranks sharing one GPU), else the launcher's LOCAL_RANK
 _device = int(os.environ.get("FS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-_contexts = {}
+_local = threading.local()      # a library context serves one call at a time: every thread keeps its own
 
 
 def set_device(index):
@@ -42,6 +43,7 @@ def set_device(index):
 
 def _context(h, w, kernel_size, max_batch=1, params=None):
     key = (_device, int(h), int(w))
+    _contexts = _local.__dict__.setdefault("contexts", {})
     ctx = _contexts.get(key)
     if ctx is None:
         ctx = _lib.Context(h, w, max_batch=max_batch, device=_device, kernel_size=kernel_size, params=params)

@@ -59,8 +59,9 @@ def calc_depth_extend_to_depth_extend_distance_ratio(data):
 
 def neighbor_lists(neighbor_counts):
     """Per surface the labels j >= 1 with more than 3 shared border pixels (process_surfaces.py:70-77)."""
-    S = len(neighbor_counts)
-    return [[j for j in range(1, S) if neighbor_counts[i][j] > 3] for i in range(S)]
+    linked = np.asarray(neighbor_counts) > 3
+    linked[:, 0] = False
+    return [np.flatnonzero(row).tolist() for row in linked]
 
 
 def calculate_nearest_points(point_sets, target_points):

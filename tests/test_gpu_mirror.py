@@ -326,3 +326,38 @@ def test_pinned_blocks_are_reused():
     _lib.release_pinned_pool()
     assert _lib._POOL_BYTES == 0 and not _lib._POOL
     assert [_lib._block_size(n) >= n for n in (1, 4096, 4097, 10 ** 6, 10 ** 9)] == [True] * 5
+
+
+def test_model_calls_from_two_threads():
+    """find_surface_model()(x) and the statistics mirror from two threads at once: the module keeps a library context per
+    thread (a context serves one call at a time), and each thread's results are those of the main thread's calls."""
+    import threading
+    from imagesegmentation_amd import find_surfaces as fs
+    from imagesegmentation_amd import process_surfaces as ps
+    frames = [fs.load_image(i) for i in (5, 64)]
+    model = fs.find_surface_model()
+
+    def run(frame):
+        data = model(frame)
+        ps.extract_information_from_surface_data_and_preprocess_surfaces(data, None)
+        return data
+
+    want = [run(f) for f in frames]
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                got[k] = run(frames[k])
+        except Exception as e:                      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for g, w in zip(got, want):
+        for k in ("surfaces", "patches", "depth_edges", "points_3d", "counts", "hist_color", "hist_angle", "depth_extend"):
+            assert np.array_equal(g[k], w[k]), k
