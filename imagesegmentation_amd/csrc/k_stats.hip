@@ -52,6 +52,20 @@ __device__ __forceinline__ void wave_histogram_add(uint32_t *__restrict__ hist, 
     }
 }
 
+// counts[key] += number of active lanes with that key, one LDS atomic per distinct key of the wave instead of one per
+// lane (lanes of a wave mostly share their label, and atomics on one LDS address go through one after the other).
+// Every lane of the wave must call this.
+__device__ __forceinline__ void wave_count_add(uint32_t *counts, int key, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int k = __builtin_amdgcn_readlane(key, __ffsll((long long)todo) - 1);
+        const unsigned long long same = __ballot(active && key == k) & todo;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&counts[k], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // CIE L*a*b* of an sRGB pixel (D65, 2-degree observer): the definition utils.rgb_to_Lab restates for
 // skimage.color.rgb2lab (utils.py:7-8 of the reference).  lin[v] = linearised channel value of byte v.
 // When the Lab image itself is not an output, only what the colour histogram needs of it leaves the kernel: the
@@ -82,8 +96,18 @@ __global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restr
     }
 }
 
+// sum of the lane numbers of a wave mask (scalar arithmetic: the mask is the same in every lane)
+__device__ __forceinline__ unsigned lane_number_sum(unsigned long long m)
+{
+    return (unsigned)(__popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) + 4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) +
+                      8 * __popcll(m & 0xff00ff00ff00ff00ull) + 16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull));
+}
+
 // relabel, int32 working copies, interior counts and position sums, patch-pixel counts per block (the input of
-// the counting sort that builds the point lists)
+// the counting sort that builds the point lists).  A wave's 64 consecutive pixels carry one to three labels, and 64
+// LDS atomics on one address go through one after the other: the wave adds up per label instead.  Its pixels are
+// consecutive, so with a frame at least a wave wide (at most one row change inside the wave) the sums of x and y over
+// a set of lanes follow from the set's mask without any exchange between lanes.
 __global__ __launch_bounds__(SB) void stats_prepare_kernel(const StatsFrame *__restrict__ frames, int32_t *__restrict__ surf32_all,
                                                            int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W)
 {
@@ -94,26 +118,56 @@ __global__ __launch_bounds__(SB) void stats_prepare_kernel(const StatsFrame *__r
     int32_t *__restrict__ surf32 = surf32_all + (size_t)blockIdx.y * N, *__restrict__ pat32 = pat32_all + (size_t)blockIdx.y * N;
     unsigned long long *__restrict__ acc = f.acc;
     for (int i = threadIdx.x; i < 4 * S; i += SB) sh[i] = 0u;
-    __syncthreads();
-    for (int k = 0; k < SPB / SB; ++k) {
+    const int lane = threadIdx.x & 63;
+    int64_t pls[SPB / SB], sls[SPB / SB];
+#pragma unroll
+    for (int k = 0; k < SPB / SB; ++k) {         // every load of the block is on its way before the first label is looked at
         const int p = blockIdx.x * SPB + k * SB + threadIdx.x;
-        if (p >= N) continue;
-        const int64_t pl = patches[p], sl = surfaces[p];
-        if (pl < 0 || pl >= S || sl < 0 || sl >= S) {          // every lane that writes stores the same value
-            *err = 1;
-            surf32[p] = 0;
-            pat32[p] = 0;
-            continue;
+        pls[k] = p < N ? patches[p] : 0;
+        sls[k] = p < N ? surfaces[p] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPB / SB; ++k) {
+        const int pw = __builtin_amdgcn_readfirstlane(blockIdx.x * SPB + k * SB + (int)(threadIdx.x & ~63u));   // the wave's first pixel
+        const int p = pw + lane;
+        const bool in = p < N;
+        const int64_t pl = pls[k], sl = sls[k];
+        const bool good = in && !(pl < 0 || pl >= S || sl < 0 || sl >= S);
+        if (in && !good) *err = 1;                             // every lane that writes stores the same value
+        const int s = good ? (pl != 0 ? (int)pl : (int)sl) : 0, q = good ? (int)pl : 0;
+        if (in) {
+            surf32[p] = s;
+            pat32[p] = q;
         }
-        const int s = pl != 0 ? (int)pl : (int)sl;
-        surf32[p] = s;
-        pat32[p] = (int)pl;
-        atomicAdd(&sh[3 * S + (int)pl], 1u);
-        const int y = p / W, x = p - y * W;
-        if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
-            atomicAdd(&sh[s], 1u);
-            atomicAdd(&sh[S + s], (uint32_t)x);
-            atomicAdd(&sh[2 * S + s], (uint32_t)y);
+        if (W >= 64) {
+            const int yw = pw / W, xw = pw - yw * W;
+            const int wrap = W - xw;                           // first lane of the next row, if below 64
+            const unsigned long long next_row = wrap < 64 ? ~0ull << wrap : 0ull;
+            const int y = yw + (lane >= wrap ? 1 : 0), x = xw + lane - (lane >= wrap ? W : 0);
+            const bool interior = good && y >= 1 && y < H - 1 && x >= 1 && x < W - 1;
+            wave_count_add(sh + 3 * S, q, good);               // patch pixels per label
+            unsigned long long todo = __ballot(interior);
+            while (todo) {                                     // interior pixels of the relabelled image and their positions
+                const int leader = __ffsll((long long)todo) - 1;
+                const int key = __builtin_amdgcn_readlane(s, leader);
+                const unsigned long long same = __ballot(interior && s == key) & todo;
+                const unsigned c = (unsigned)__popcll(same), c_next = (unsigned)__popcll(same & next_row);
+                if (lane == 0) {
+                    atomicAdd(&sh[key], c);
+                    atomicAdd(&sh[S + key], c * (unsigned)xw + lane_number_sum(same) - c_next * (unsigned)W);
+                    atomicAdd(&sh[2 * S + key], c * (unsigned)yw + c_next);
+                }
+                todo &= ~same;
+            }
+        } else if (good) {                                     // narrow frames: a wave spans several rows
+            atomicAdd(&sh[3 * S + q], 1u);
+            const int y = p / W, x = p - y * W;
+            if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+                atomicAdd(&sh[s], 1u);
+                atomicAdd(&sh[S + s], (uint32_t)x);
+                atomicAdd(&sh[2 * S + s], (uint32_t)y);
+            }
         }
     }
     __syncthreads();

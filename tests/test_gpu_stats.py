@@ -217,3 +217,29 @@ def test_process_surfaces_mirror_converts_colours_on_the_device(oracle):
               "depth_extend_distances"):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
     assert a["neighbors"] == b["neighbors"]
+
+
+@pytest.mark.parametrize("shape", [(40, 100), (37, 64), (21, 191)])
+def test_surface_stats_rows_that_end_inside_a_wave(oracle, shape):
+    """Frame widths that are not a multiple of 64: the lanes of a wave then lie in two rows, which the per-label position
+    sums of the preparation pass have to take into account.  Random blocky labelling, every output against the oracle."""
+    from imagesegmentation_amd._lib import Context
+    H, W = shape
+    S = 7
+    rng = np.random.default_rng(H * 1000 + W)
+    cells = rng.integers(0, S, size=(H // 9 + 1, W // 11 + 1))
+    i, j = np.mgrid[0:H, 0:W]
+    surfaces = cells[i // 9, j // 11].astype(np.int64)
+    patches = np.where((i % 9 > 1) & (j % 11 > 2) & (rng.random((H, W)) < 0.8), surfaces, 0).astype(np.int64)
+    edges = (rng.random((H, W)) < 0.9).astype(np.int32)
+    pts = rng.normal(size=(H, W, 3)).astype(np.float32) * 100
+    ang = (rng.random((H, W, 2), dtype=np.float32) - 0.5) * 6
+    lab = np.stack([rng.random((H, W)) * 100, rng.random((H, W)) * 200 - 100, rng.random((H, W)) * 200 - 100], -1)
+    args = (surfaces, patches, edges, pts, ang, lab, None, S)
+    want = oracle.surface_stats(*args)
+    with Context(H, W) as ctx:
+        got = ctx.surface_stats(*args)
+    for k in ("surfaces", "patch_point_offsets", "patch_points", "avg_pos", "counts", "centroids", "centroid_indices",
+              "hist_color", "hist_angle", "neighbor_counts", "border_centers", "norm", "depth_extend"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.allclose(got["avg_angles"], want["avg_angles"], rtol=1e-12, atol=1e-13)
