@@ -1307,8 +1307,11 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
                 const double c = (double)v / 255.0;
                 lin[v] = c > 0.04045 ? std::pow((c + 0.055) / 1.055, 2.4) : c / 12.92;
             }
-            FS_HIP(ctx->st_lin.ensure(sizeof(lin)));
+            float lin32[256];                                  // the same values in float32 behind them
+            for (int v = 0; v < 256; ++v) lin32[v] = (float)lin[v];
+            FS_HIP(ctx->st_lin.ensure(sizeof(lin) + sizeof(lin32)));
             FS_HIP(hipMemcpy(ctx->st_lin.p, lin, sizeof(lin), hipMemcpyHostToDevice));
+            FS_HIP(hipMemcpy((char *)ctx->st_lin.p + sizeof(lin), lin32, sizeof(lin32), hipMemcpyHostToDevice));
         }
     }
     char *p = ctx->st_out.as<char>();
@@ -1329,6 +1332,7 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
     }
     char *zero = ctx->st_scratch.as<char>(), *ones = zero + up(tot.zero), *ext = ones + up(tot.ones), *plain = ext + up(tot.ext);
     w.lin = ctx->st_lin.as<double>();
+    w.lin32 = reinterpret_cast<const float *>(w.lin + 256);
     w.ext_all = reinterpret_cast<uint32_t *>(ext);
     w.ext_words = tot.ext / 4;
     w.err = d_err;

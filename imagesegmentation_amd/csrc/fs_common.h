@@ -150,6 +150,7 @@ struct StatsFrame {
 struct StatsBatchWork {
     int32_t *surf32, *pat32, *parent, *count;   // [n][H*W] each
     const double *lin;                          // [256] linearised sRGB channel values
+    const float *lin32;                         // [256] the same, rounded to float32
     uint32_t *ext_all;                          // the batch's min / max slots
     size_t ext_words;
     int *err;                                   // 0 ok, 1 label out of range, 2 colour bin out of range, 3 angle bin out of range

@@ -70,30 +70,102 @@ __device__ __forceinline__ void wave_count_add(uint32_t *counts, int key, bool a
 // skimage.color.rgb2lab (utils.py:7-8 of the reference).  lin[v] = linearised channel value of byte v.
 // When the Lab image itself is not an output, only what the colour histogram needs of it leaves the kernel: the
 // pixel's bin round(a + 127) << 8 | round(b + 127) (process_surfaces.py:265-267), 4 bytes instead of 24 written and 16 read.
-__global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin, int N,
-                                                       int *__restrict__ err)
+//
+// The bins alone do not need float64: a and b in float32 are off by less than 3e-4 (the cube roots carry an absolute
+// error below 2.5e-7 each -- 2^-24 relative in the table, three more roundings in the matrix product, a third of their sum
+// through the root plus the root's own two units -- times 500 for a, 200 for b, plus 2e-5 of rounding in the difference
+// and the offset), so a pixel whose a + 127 and b + 127 both lie further than kLabBand from a rounding boundary, and
+// whose X, Y, Z stay clear of the switch between root and straight line, gets its bins from float32; the others (one
+// in four hundred) go through the float64 evaluation.  All 2^24 colours are enumerated by the tests.
+constexpr float kLabBand = 6e-4f;
+
+__device__ __forceinline__ bool lab_bins_float(float r, float g, float b, int &bin_a, int &bin_b)
 {
-    const StatsFrame &f = frames[blockIdx.y];
-    const int p = blockIdx.x * SB + threadIdx.x;
-    if (p >= N || !f.rgb) return;
-    const double r = lin[f.rgb[3 * (size_t)p]], g = lin[f.rgb[3 * (size_t)p + 1]], b = lin[f.rgb[3 * (size_t)p + 2]];
+    const float x = fmaf(b, 0.180423f, fmaf(g, 0.357580f, r * 0.412453f)) / 0.95047f;
+    const float y = fmaf(b, 0.072169f, fmaf(g, 0.715160f, r * 0.212671f));
+    const float z = fmaf(b, 0.950227f, fmaf(g, 0.119193f, r * 0.019334f)) / 1.08883f;
+    const float v[3] = {x, y, z};
+    float t[3];
+    bool clear = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        clear &= fabsf(v[c] - 0.008856f) > 1e-6f;
+        t[c] = v[c] > 0.008856f ? cbrtf(v[c]) : fmaf(7.787f, v[c], 16.0f / 116.0f);
+    }
+    const float av = fmaf(500.0f, t[0] - t[1], 127.0f), bv = fmaf(200.0f, t[1] - t[2], 127.0f);
+    const float fa = av - floorf(av), fb = bv - floorf(bv);
+    clear &= fabsf(fa - 0.5f) > kLabBand && fabsf(fb - 0.5f) > kLabBand;
+    bin_a = (int)rintf(av);
+    bin_b = (int)rintf(bv);
+    return clear;
+}
+
+__device__ __forceinline__ void lab_float64(double r, double g, double b, double &L, double &a_, double &b_)
+{
     const double xyz[3] = {((r * 0.412453 + g * 0.357580) + b * 0.180423) / 0.95047, ((r * 0.212671 + g * 0.715160) + b * 0.072169) / 1.0,
                            ((r * 0.019334 + g * 0.119193) + b * 0.950227) / 1.08883};
     double t[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) t[c] = xyz[c] > 0.008856 ? cbrt(xyz[c]) : 7.787 * xyz[c] + 16.0 / 116.0;
-    const double a_ = 500.0 * (t[0] - t[1]), b_ = 200.0 * (t[1] - t[2]);
-    if (f.lab_work) {
-        double *o = f.lab_work + 3 * (size_t)p;
-        o[0] = 116.0 * t[1] - 16.0;
-        o[1] = a_;
-        o[2] = b_;
+    L = 116.0 * t[1] - 16.0;
+    a_ = 500.0 * (t[0] - t[1]);
+    b_ = 200.0 * (t[1] - t[2]);
+}
+
+// the Lab image of the frames that want one
+__global__ __launch_bounds__(SB) void stats_lab_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin, int N)
+{
+    const StatsFrame &f = frames[blockIdx.y];
+    const int p = blockIdx.x * SB + threadIdx.x;
+    if (p >= N || !f.rgb || !f.lab_work) return;
+    double *o = f.lab_work + 3 * (size_t)p;
+    lab_float64(lin[f.rgb[3 * (size_t)p]], lin[f.rgb[3 * (size_t)p + 1]], lin[f.rgb[3 * (size_t)p + 2]], o[0], o[1], o[2]);
+}
+
+// the colour bins of the frames that do not: four pixels per lane (twelve colour bytes in three words when the image
+// is aligned for that, one 16-byte store), the two tables in LDS
+__global__ __launch_bounds__(SB) void stats_color_bins_kernel(const StatsFrame *__restrict__ frames, const double *__restrict__ lin,
+                                                              const float *__restrict__ lin32, int N)
+{
+    __shared__ double s_lin[256];
+    __shared__ float s_lin32[256];
+    const StatsFrame &f = frames[blockIdx.y];
+    if (!f.rgb || f.lab_work) return;
+    static_assert(SB == 256, "one table entry per thread");
+    s_lin[threadIdx.x] = lin[threadIdx.x];
+    s_lin32[threadIdx.x] = lin32[threadIdx.x];
+    __syncthreads();
+    const int p0 = 4 * (blockIdx.x * SB + (int)threadIdx.x);
+    if (p0 >= N) return;
+    const uint8_t *__restrict__ rgb = f.rgb + 3 * (size_t)p0;
+    uint8_t c[12];
+    const bool whole = p0 + 4 <= N;
+    if (whole && ((uintptr_t)rgb & 3u) == 0) {
+        const uint32_t w0 = reinterpret_cast<const uint32_t *>(rgb)[0], w1 = reinterpret_cast<const uint32_t *>(rgb)[1],
+                       w2 = reinterpret_cast<const uint32_t *>(rgb)[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = (uint8_t)(w0 >> (8 * k)); c[4 + k] = (uint8_t)(w1 >> (8 * k)); c[8 + k] = (uint8_t)(w2 >> (8 * k)); }
     } else {
-        const long a = (long)rint(a_ + 127.0), b = (long)rint(b_ + 127.0);
-        const bool ok = a >= 0 && a <= 255 && b >= 0 && b <= 255;
-        f.color_bin[p] = ok ? (uint32_t)(a * 256 + b) : 0xffffffffu;      // (an sRGB colour never leaves the range; the
-        (void)err;                                                        // accumulation pass reports the flag if one does)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) c[k] = p0 + k / 3 < N ? rgb[k] : 0;
     }
+    uint32_t bins[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int a, b;
+        if (!lab_bins_float(s_lin32[c[3 * k]], s_lin32[c[3 * k + 1]], s_lin32[c[3 * k + 2]], a, b)) {
+            double L, a_, b_;
+            lab_float64(s_lin[c[3 * k]], s_lin[c[3 * k + 1]], s_lin[c[3 * k + 2]], L, a_, b_);
+            a = (int)rint(a_ + 127.0);
+            b = (int)rint(b_ + 127.0);
+        }
+        // (an sRGB colour never leaves the range; the accumulation pass reports the flag if one does)
+        bins[k] = a >= 0 && a <= 255 && b >= 0 && b <= 255 ? (uint32_t)(a * 256 + b) : 0xffffffffu;
+    }
+    uint32_t *out = f.color_bin + p0;
+    if (whole && ((uintptr_t)out & 15u) == 0) *reinterpret_cast<uint4 *>(out) = make_uint4(bins[0], bins[1], bins[2], bins[3]);
+    else
+        for (int k = 0; k < 4 && p0 + k < N; ++k) out[k] = bins[k];
 }
 
 // sum of the lane numbers of a wave mask (scalar arithmetic: the mask is the same in every lane)
@@ -647,16 +719,19 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     const int N = H * W;
     const int nblk = stats_blocks_per_frame(H, W);
     int Smax = 1;
-    bool any_rgb = false, any_texture = false;
+    bool any_rgb = false, any_texture = false, any_lab_out = false, any_bins_only = false;
     for (int i = 0; i < n; ++i) {
         Smax = std::max(Smax, frames_host[i].S);
         any_rgb |= frames_host[i].rgb != nullptr;
+        any_lab_out |= frames_host[i].rgb && frames_host[i].lab_work;
+        any_bins_only |= frames_host[i].rgb && !frames_host[i].lab_work;
         any_texture |= frames_host[i].texture != nullptr;
     }
     const dim3 by_pixel((N + SB - 1) / SB, n), by_block(nblk, n);
     hipLaunchKernelGGL(stats_fill_kernel, dim3((unsigned)((w.ext_words + SB - 1) / SB)), dim3(SB), 0, st, w.ext_all, w.ext_words, ~0u, 0u);
     if (any_rgb && after_stage) after_stage(10);
-    if (any_rgb) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N, w.err);
+    if (any_lab_out) hipLaunchKernelGGL(stats_lab_kernel, by_pixel, dim3(SB), 0, st, frames, w.lin, N);
+    if (any_bins_only) hipLaunchKernelGGL(stats_color_bins_kernel, dim3((N + 4 * SB - 1) / (4 * SB), n), dim3(SB), 0, st, frames, w.lin, w.lin32, N);
     if (any_rgb && after_stage) after_stage(0);
     if (after_stage) after_stage(11);
     hipLaunchKernelGGL(stats_prepare_kernel, by_block, dim3(SB), 4 * Smax * sizeof(uint32_t), st, frames, w.surf32, w.pat32, w.err, H, W);

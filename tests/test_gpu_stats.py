@@ -243,3 +243,65 @@ def test_surface_stats_rows_that_end_inside_a_wave(oracle, shape):
               "hist_color", "hist_angle", "neighbor_counts", "border_centers", "norm", "depth_extend"):
         assert np.array_equal(got[k], want[k]), k
     assert np.allclose(got["avg_angles"], want["avg_angles"], rtol=1e-12, atol=1e-13)
+
+
+def test_colour_bins_of_all_sRGB_colours():
+    """Every one of the 2^24 colours through the device's colour conversion, as 64 frames of 512 x 512 pixels with one
+    label: the colour histogram must hold exactly the bins that utils.rgb_to_Lab's float64 values round to.  Without a
+    Lab output the kernel takes the bins from a float32 evaluation unless a value lies close to a rounding boundary;
+    with one it evaluates in float64 throughout.  Both ways are enumerated."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.utils import rgb_to_Lab
+    H = W = 512
+    n, S = 16, 2
+    N = H * W
+    dev = DeviceArrays()
+    try:
+        with Context(H, W, max_batch=n) as ctx:
+            ones64 = dev.upload(np.ones((n, H, W), np.int64))
+            edges = dev.upload(np.zeros((n, H, W), np.int32))
+            pts = dev.upload(np.ones((n, H, W, 3), np.float32))
+            ang = dev.upload(np.zeros((n, H, W, 2), np.float32))
+            d_hist = dev.alloc(n * 65536 * S * 8)
+            d_lab = dev.alloc(n * N * 24)
+            for call in range(2 ** 24 // (n * N)):
+                v = np.arange(call * n * N, (call + 1) * n * N, dtype=np.uint32)
+                rgb = np.stack([v >> 16, (v >> 8) & 255, v & 255], -1).astype(np.uint8).reshape(n, H, W, 3)
+                lab = rgb_to_Lab(rgb)
+                bins = (np.rint(lab[..., 1] + 127.0).astype(np.int64) * 256 + np.rint(lab[..., 2] + 127.0).astype(np.int64)).reshape(n, N)
+                want = np.stack([np.bincount(b, minlength=65536) for b in bins]).astype(np.float64)
+                d_rgb = dev.upload(rgb)
+                for lab_out in (None, d_lab):
+                    ctx.surface_stats_batch_dev([S] * n, ones64, ones64, edges, pts, ang, d_rgb=d_rgb, d_lab_out=lab_out, hist_color=d_hist)
+                    ctx.synchronize()
+                    got = np.rint(dev.download(d_hist, np.empty((n, 65536, S), np.float64)) * (N / 10))      # counts over a tenth of the label's pixels
+                    assert not got[:, :, 0].any()
+                    assert np.array_equal(got[:, :, 1], want), (call, lab_out is not None)
+    finally:
+        dev.free()
+
+
+def test_colour_bins_of_frames_with_ragged_sizes():
+    """Frames whose pixel count is not a multiple of four (the bins-only colour pass takes four pixels per lane and the
+    second frame's colours do not start on a word boundary): same colour histograms as with a Lab image as an output,
+    which takes the one-pixel-per-lane float64 pass."""
+    from imagesegmentation_amd._lib import Context
+    H, W, n, S = 21, 191, 3, 5
+    N = H * W
+    rng = np.random.default_rng(7)
+    surfaces = rng.integers(1, S, size=(n, H // 7 + 1, W // 16 + 1))[:, np.arange(H)[:, None] // 7, np.arange(W)[None, :] // 16].astype(np.int64)
+    rgb = rng.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8)
+    dev = DeviceArrays()
+    try:
+        with Context(H, W, max_batch=n) as ctx:
+            args = (dev.upload(surfaces), dev.upload(surfaces), dev.upload(np.zeros((n, H, W), np.int32)),
+                    dev.upload(np.ones((n, H, W, 3), np.float32)), dev.upload(np.zeros((n, H, W, 2), np.float32)))
+            d_rgb, d_hist, d_lab = dev.upload(rgb), dev.alloc(n * 65536 * S * 8), dev.alloc(n * N * 24)
+            hists = []
+            for lab_out in (None, d_lab):
+                ctx.surface_stats_batch_dev([S] * n, *args, d_rgb=d_rgb, d_lab_out=lab_out, hist_color=d_hist)
+                ctx.synchronize()
+                hists.append(dev.download(d_hist, np.empty((n, 65536, S), np.float64)))
+    finally:
+        dev.free()
+    assert hists[0].any() and np.array_equal(hists[0], hists[1])
