@@ -147,7 +147,7 @@ bool host_memory_is_page_locked(const void *p)
 // drained, so the block is free again when the next call begins.
 class StagedSources {
   public:
-    StagedSources(fs_ctx *c, HostBuf &b) : ctx_(c), buf_(b) {}
+    explicit StagedSources(HostBuf &b) : buf_(b) {}
     void want(const void *src, size_t bytes)
     {
         if (bytes && !host_memory_is_page_locked(src)) total_ += (bytes + 255) / 256 * 256;
@@ -171,7 +171,6 @@ class StagedSources {
     }
 
   private:
-    fs_ctx *ctx_;
     HostBuf &buf_;
     size_t total_ = 0, used_ = 0;
 };
@@ -1198,7 +1197,7 @@ int fs_apply_crf(fs_ctx *ctx, int n, const int64_t *labels, const uint16_t *dept
     if (!ctx->have_params) return ctx->fail("fs_apply_crf: call fs_set_gauss_params first");
     if (!labels || !depth || !rgb || !angles || !out) return ctx->fail("fs_apply_crf: null argument");
     const size_t N = ctx->N(), px = (size_t)n * N;
-    StagedSources up(ctx, ctx->stats_in_host);
+    StagedSources up(ctx->stats_in_host);
     const bool out_locked = host_memory_is_page_locked(out);
     if (!out_locked) up.want_block(px * 8);                 // a pageable result array is filled from page-locked memory as well
     up.want(labels, px * 8);
@@ -1607,7 +1606,7 @@ int fs_chi_squared_distances(fs_ctx *ctx, const double *hist, int A, int B, int 
     FS_HIP(ctx->st_in.ensure(in_bytes));
     FS_HIP(ctx->st_scratch.ensure(pooled_bytes));
     FS_HIP(ctx->st_out.ensure(out_bytes));
-    StagedSources up(ctx, ctx->stats_in_host);
+    StagedSources up(ctx->stats_in_host);
     up.want(hist, in_bytes);
     FS_HIP(up.begin());
     FS_HIP(hipMemcpyAsync(ctx->st_in.p, up.from(hist, in_bytes), in_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1649,7 +1648,7 @@ int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *det
     int64_t *d_a = ctx->st_in.as<int64_t>(), *d_o = d_a + N;
     unsigned *d_ov = ctx->st_out.as<unsigned>();
     int *d_err = reinterpret_cast<int *>(d_ov + cells);
-    StagedSources up(ctx, ctx->stats_in_host);
+    StagedSources up(ctx->stats_in_host);
     up.want(annotation, N * 8);
     up.want(detected, N * 8);
     FS_HIP(up.begin());

@@ -109,3 +109,26 @@ def extract_information_from_surface_data_and_preprocess_surfaces(data, texture_
     data["depth_extend_distances"] = create_depth_extend_distance_matrix(data) / 1000
     data["depth_extend_distance_ratio"] = calc_depth_extend_to_depth_extend_distance_ratio(data)
     return data
+
+
+_pools = {}
+
+
+def extract_information_for_frames(frames, texture_model, workers=2):
+    """The per-frame function above over a list of frames' dicts, from `workers` threads (the loops of the reference's
+    callers over a data set's images reach it one frame after the other: process_surfaces.py:748-751,
+    assemble_objects_rules.py:129-131).  A frame's results are about twice its inputs in bytes and one call sends the
+    inputs up before the results come down; two calls in flight, each thread with a library context of its own, use
+    both directions of the link at once.  The threads stay (a context costs more to set up than dozens of frames to
+    process).  Fills the dicts in place and returns the list."""
+    frames = list(frames)
+    if workers <= 1 or len(frames) <= 1:
+        for data in frames:
+            extract_information_from_surface_data_and_preprocess_surfaces(data, texture_model)
+        return frames
+    pool = _pools.get(workers)
+    if pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = _pools[workers] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="fs-stats")
+    list(pool.map(lambda data: extract_information_from_surface_data_and_preprocess_surfaces(data, texture_model), frames))
+    return frames

@@ -305,3 +305,23 @@ def test_colour_bins_of_frames_with_ragged_sizes():
     finally:
         dev.free()
     assert hists[0].any() and np.array_equal(hists[0], hists[1])
+
+
+def test_process_surfaces_mirror_over_a_list_of_frames():
+    """extract_information_for_frames: the per-frame function from several threads, a library context per thread; every
+    frame's results are those of calling the per-frame function on it alone."""
+    from imagesegmentation_amd import find_surfaces as fs
+    from imagesegmentation_amd import process_surfaces as ps
+    model = fs.find_surface_model("Gauss")
+    base = [model(fs.load_image(i)) for i in (3, 20, 57, 88, 110)]
+    alone = [ps.extract_information_from_surface_data_and_preprocess_surfaces(dict(d), None) for d in base]
+    for workers in (1, 3, 3):
+        frames = ps.extract_information_for_frames([dict(d) for d in base], None, workers=workers)
+        for got, want in zip(frames, alone):
+            assert got.keys() == want.keys()
+            for k in ("surfaces", "lab", "counts", "avg_pos", "centroids", "hist_color", "hist_angle", "norm", "depth_extend",
+                      "planes", "border_centers"):
+                assert np.array_equal(got[k], want[k]), (workers, k)
+            assert got["neighbors"] == want["neighbors"]
+            assert np.allclose(got["avg_normals"], want["avg_normals"], rtol=0, atol=1e-12, equal_nan=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got["patch_points"], want["patch_points"]))

@@ -99,6 +99,17 @@ def main(args):
                                 "note": "process_surfaces.extract_information_from_surface_data_and_preprocess_surfaces per frame: numpy "
                                         "arrays in, numpy arrays out (PCIe both ways, S x S tails in numpy), each frame's results "
                                         "released before the next call"}
+    # the same function over a list of frames, two calls in flight (results kept until the list is done)
+    many = [datas[i % len(datas)] for i in range(24)]
+    for _ in range(4):              # (the workers' contexts and the page-locked blocks grow to the frames' sizes in the first rounds)
+        frames = [dict(dct) for dct in many]
+        t1 = time.perf_counter()
+        ps.extract_information_for_frames(frames, None, workers=2)
+        dt_list = time.perf_counter() - t1
+        del frames
+    out["value_host_mirror_list"] = {"value": len(many) / dt_list, "unit": "frames/s",
+                                     "note": "process_surfaces.extract_information_for_frames over 24 frames' dicts, two worker "
+                                             "threads with a library context each: uploads of one frame beside downloads of another"}
     if want_cpu:
         from imagesegmentation_amd.utils import rgb_to_Lab
         os.environ["OMP_NUM_THREADS"] = "1"
