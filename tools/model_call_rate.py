@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rate of the reference's in-memory entry point, find_surface_model()(x) (find_surfaces.py:563-565): one frame per
 call, numpy arrays in, the dict of numpy arrays out, each result released before the next call (as a caller that
-processes frame after frame does).  Also the same frames through Context.find_surfaces_batch with page-locked inputs.
+processes frame after frame does).  Also the same frames through Context.find_surfaces_batch with page-locked inputs,
+and the model called from two and three threads at once.
 
     python tools/model_call_rate.py [--calls 300]
 """
@@ -50,6 +51,27 @@ def main():
     dt = time.perf_counter() - t0
     res["pinned_in_and_out_calls_per_s"] = args.calls / dt
     res["pinned_ms_per_call"] = 1e3 * dt / args.calls
+    # the same entry point from several threads at once (a server's worker threads): the module keeps a library
+    # context per thread, and one thread's downloads run beside another's kernels
+    import threading
+    for workers in (2, 3):
+        took = [0.0] * workers
+
+        def work(k):
+            for f in frames[:4]:
+                model(f)                    # the thread's context and its buffers come into being
+            t = time.perf_counter()
+            for j in range(args.calls):
+                out = model(frames[(j + k) % len(frames)])
+                del out
+            took[k] = time.perf_counter() - t
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(workers)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        res[f"find_surface_model_calls_per_s_{workers}_threads"] = sum(args.calls / t for t in took)
     print(json.dumps(res))
 
 
