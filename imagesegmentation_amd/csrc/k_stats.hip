@@ -23,6 +23,7 @@ namespace {
 
 constexpr int SB = 256;            // threads per block
 constexpr int SPB = 1024;          // pixels per block (4 per thread, interleaved for coalescing)
+constexpr int kWinSlots = 8;       // labels per block of the accumulation pass whose colour counts are gathered in LDS
 
 __device__ __forceinline__ unsigned enc_f32(float f)      // order-preserving float -> unsigned
 {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(SB) void stats_keep_kernel(const StatsFrame *__rest
 // histograms, angle sums, neighbour counts and border sums, norm and per-label extents
 __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *__restrict__ frames, const int32_t *__restrict__ surf32_all,
                                                               const int32_t *__restrict__ pat32_all, int *__restrict__ err, int H, int W,
-                                                              int pixels_per_block)
+                                                              int pixels_per_block, int window_table)
 {
     const StatsFrame &f = frames[blockIdx.y];
     const int S = f.S;
@@ -454,9 +455,22 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
     double *s_ang = shd;
     uint32_t *she = reinterpret_cast<uint32_t *>(shd + 2 * S);
     uint32_t *s_cnt = she + 8 * S, *p_cnt = s_cnt + S;
+    // Colour counts of a fat block (window_table): a surface's colours lie close together, so the first kWinSlots labels
+    // the block meets get a window of 32 x 32 bins each in LDS, placed around the first colour seen of the label, with
+    // 16-bit counters (a block has at most 8 192 pixels); a pixel inside its label's window costs an LDS atomic, the
+    // windows go to the frame's histogram once at the block's end (a few hundred global atomics instead of a few
+    // thousand), and pixels outside, or of a label without a window, add to the frame's histogram directly as before.
+    int *win_slot = reinterpret_cast<int *>(p_cnt + S);               // [S] slot of a label: -1 none yet, -2 being set up, -3 none left
+    int *win_origin = win_slot + S, *win_label = win_origin + kWinSlots, *win_used = win_label + kWinSlots;
+    uint32_t *win_tab = reinterpret_cast<uint32_t *>(win_used + 1);   // [kWinSlots][32][32] counters, two per word
     const int N = H * W;
     for (int i = threadIdx.x; i < 8 * S; i += SB) she[i] = (i & 1) ? 0u : ~0u;
     for (int i = threadIdx.x; i < 2 * S; i += SB) { s_cnt[i] = 0u; s_ang[i] = 0.0; }
+    if (window_table) {
+        for (int i = threadIdx.x; i < S; i += SB) win_slot[i] = -1;
+        for (int i = threadIdx.x; i < kWinSlots * 512; i += SB) win_tab[i] = 0u;
+        if (threadIdx.x == 0) *win_used = 0;
+    }
     __syncthreads();
     for (int k = 0; k < pixels_per_block / SB; ++k) {
         const int p = blockIdx.x * pixels_per_block + k * SB + threadIdx.x;
@@ -482,14 +496,39 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
         }
         if (s > 0) {
             // colour histogram, :265-267
+            uint32_t ab;
             if (color_bin_of) {
-                const uint32_t ab = color_bin_of[p];
-                if (ab == 0xffffffffu) *err = 2;
-                else { color_on = true; color_bin = ab * (uint32_t)S + (uint32_t)s; }
+                ab = color_bin_of[p];
             } else {
                 const long a = (long)rint(lab[3 * (size_t)p + 1] + 127.0), b = (long)rint(lab[3 * (size_t)p + 2] + 127.0);
-                if (a < 0 || a > 255 || b < 0 || b > 255) *err = 2;
-                else { color_on = true; color_bin = (uint32_t)((a * 256 + b) * S + s); }
+                ab = a < 0 || a > 255 || b < 0 || b > 255 ? 0xffffffffu : (uint32_t)(a * 256 + b);
+            }
+            if (ab == 0xffffffffu) *err = 2;
+            else { color_on = true; color_bin = ab * (uint32_t)S + (uint32_t)s; }
+            if (window_table && color_on) {
+                const int a = (int)(ab >> 8), b = (int)(ab & 255u);
+                int slot = win_slot[s];
+                if (slot == -1 && atomicCAS(&win_slot[s], -1, -2) == -1) {        // this lane sets the label's window up
+                    const int k = atomicAdd(win_used, 1);
+                    if (k < kWinSlots) {
+                        win_origin[k] = min(max(a - 16, 0), 224) << 8 | min(max(b - 16, 0), 224);
+                        win_label[k] = s;
+                        __threadfence_block();
+                        slot = k;
+                    } else {
+                        slot = -3;
+                    }
+                    __hip_atomic_store(&win_slot[s], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (slot >= 0) {
+                    const int o = win_origin[slot];
+                    const unsigned da = (unsigned)(a - (o >> 8)), db = (unsigned)(b - (o & 255));
+                    if (da < 32u && db < 32u) {
+                        const unsigned idx = (unsigned)slot * 1024u + da * 32u + db;
+                        atomicAdd(&win_tab[idx >> 1], 1u << (16u * (idx & 1u)));
+                        color_on = false;                                        // counted
+                    }
+                }
             }
             atomicAdd(&s_cnt[s], 1u);
             // neighbours, :39-55 (pairs with label 0 and pairs of equal labels are zeroed afterwards: skipped)
@@ -535,6 +574,20 @@ __global__ __launch_bounds__(SB) void stats_accumulate_kernel(const StatsFrame *
     for (int i = threadIdx.x; i < 2 * S; i += SB) {
         if (s_cnt[i]) atomicAdd(cnt + i, s_cnt[i]);
         if (s_ang[i] != 0.0) atomicAdd(angle_sum + i, s_ang[i]);
+    }
+    if (window_table) {
+        const int used = min(*win_used, kWinSlots);
+        for (int i = threadIdx.x; i < used * 512; i += SB) {
+            const uint32_t w = win_tab[i];
+            if (!w) continue;
+            const int slot = i >> 9, o = win_origin[slot], label = win_label[slot];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t v = (w >> (16 * h)) & 0xffffu;
+                const int idx = 2 * i + h, a = (o >> 8) + ((idx >> 5) & 31), b = (o & 255) + (idx & 31);
+                if (v) atomicAdd(hist_color + (size_t)(a * 256 + b) * S + label, v);
+            }
+        }
     }
 }
 
@@ -752,8 +805,11 @@ hipError_t launch_surface_stats_batch(const StatsFrame *frames, const StatsFrame
     // in all, between 256 and 8 192 pixels each.
     int acc_ppb = SB;
     while (acc_ppb < 8192 && (size_t)n * N / (2 * (size_t)acc_ppb) >= 4096) acc_ppb *= 2;
+    const int window_table = acc_ppb >= 2048;      // (setting the windows up and sweeping them costs a block about what 500 pixels do)
     hipLaunchKernelGGL(stats_accumulate_kernel, dim3((N + acc_ppb - 1) / acc_ppb, n), dim3(SB),
-                       10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double), st, frames, w.surf32, w.pat32, w.err, H, W, acc_ppb);
+                       10 * Smax * sizeof(uint32_t) + 2 * Smax * sizeof(double) +
+                           (window_table ? (Smax + 2 * kWinSlots + 1 + kWinSlots * 512) * sizeof(uint32_t) : 0),
+                       st, frames, w.surf32, w.pat32, w.err, H, W, acc_ppb, window_table);
     if (any_texture)
         hipLaunchKernelGGL(stats_texture_kernel, dim3(H / 4, n), dim3(SB), 0, st, frames, w.surf32, w.pat32, N, W, W / 4, T);
     const size_t n_fin = std::max<size_t>((size_t)256 * 256 * Smax / 4, std::max<size_t>((size_t)Smax * T, (size_t)1600 * Smax));   // lanes: four colour bins each
