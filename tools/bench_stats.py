@@ -83,6 +83,10 @@ def main(args):
                         "frac": float(alg.sum()) * args.steps / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes": float(alg.mean()), "avg_us": 1e6 * dt / (n * args.steps),
                         "note": "host wall time of the batched call (one synchronisation per call), not a kernel duration"}}
+    if args.no_host_leg:            # (a kernel trace of the batched stage alone)
+        print(json.dumps(out), flush=True)
+        ctx.close()
+        return
     # the per-frame host-pointer mirror, as the reference's callers use the function
     from imagesegmentation_amd import find_surfaces as fs
     from imagesegmentation_amd import process_surfaces as ps

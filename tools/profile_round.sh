@@ -20,7 +20,7 @@ trace osd_one_frame --frames 1 --steps 200 --warmup 5 --no-host-leg --no-kernel-
 trace m1280_s32_r7 --workload mosaic1280 --labels 32 --kernel-size 7 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s32_r10 --workload mosaic1280 --labels 32 --kernel-size 10 --steps 3 --warmup 1 --no-host-leg
 trace m1280_s64_r15 --workload mosaic1280 --labels 64 --kernel-size 15 --steps 3 --warmup 1 --no-host-leg
-trace stats --stage stats --steps 5 --warmup 2
+trace stats --stage stats --steps 5 --warmup 2 --no-host-leg
 pmc() {     # name, counters, bench args...
   local name=$1 ctrs=$2; shift 2
   mkdir -p "$out/pmc_$name"
