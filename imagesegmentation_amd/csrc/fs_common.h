@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -35,6 +36,11 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess && want != bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
         if (e == hipSuccess) cap = want;
+        // A new buffer starts as zeros, whatever the allocator hands out (memory that another context of the process
+        // has freed keeps its contents): a value that a kernel multiplies by a weight of exactly zero -- the
+        // probabilities of a neighbour without depth, say -- must not be the NaN that old integer data reads as.
+        if (e == hipSuccess) e = hipMemset(p, 0, want);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (done before a kernel on another stream writes there)
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }

@@ -42,6 +42,10 @@ def _checker_scene(H, W, cell=20):
 def _same(a, b, what):
     assert np.array_equal(a["num_surfaces"], b["num_surfaces"]), what
     for k in KEYS:
+        if not np.array_equal(a[k], b[k]):
+            bad = np.argwhere(np.asarray(a[k]) != np.asarray(b[k]))
+            print("DIFF", what, k, "count", len(bad), "min", bad.min(0), "max", bad.max(0), "first", bad[:5].tolist(),
+                  "a", np.asarray(a[k])[tuple(bad[0])], "b", np.asarray(b[k])[tuple(bad[0])], flush=True)
         assert np.array_equal(a[k], b[k]), f"{what}: {k}"
 
 
@@ -175,3 +179,24 @@ def test_small_host_calls_with_and_without_early_downloads():
             _same(got, ref, what)
             for i in range(n):
                 _same(ctx.find_surfaces_batch(depth[i], rgb[i]), {k: ref[k][i] for k in KEYS + ("num_surfaces",)}, f"{what}, frame {i}")
+
+
+def test_results_do_not_depend_on_what_freed_memory_held():
+    """Device memory that the process has freed comes back from the allocator with its old contents.  A context's
+    buffers start as zeros all the same: fill a gigabyte with all-ones bytes (NaN as floats), free it, create a
+    context in its place and compare with a context that was created before."""
+    from conftest import DeviceArrays
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch, make_scene
+    H, W = 480, 640
+    one = make_scene(5, H, W)
+    d, c = make_batch([81, 82, 83], H, W)
+    with Context(H, W, max_batch=3) as before:
+        ref_one, ref_batch = before.find_surfaces_batch(*one), before.find_surfaces_batch(d, c)
+    dirty = DeviceArrays()
+    for _ in range(8):
+        dirty.alloc(128 << 20, fill=0xFF)
+    dirty.free()
+    with Context(H, W, max_batch=3) as after:
+        _same(after.find_surfaces_batch(*one), ref_one, "one frame")
+        _same(after.find_surfaces_batch(d, c), ref_batch, "three frames")
