@@ -181,6 +181,28 @@ int set_device(fs_ctx *ctx)
     return 0;
 }
 
+// FS_DEBUG_NAN=<letters>: float work buffers named by the letters are filled with NaN in front of every find_surfaces
+// call (q: both sets of probability planes, a / b: the two halves of the feature records, s: smoothed depth, r: raw
+// angles; t: the tile records of the CRF update, as -1), so that a kernel that reads a value nobody wrote in this call
+// shows up in the results.
+int debug_nan_fill(fs_ctx *ctx)
+{
+    const char *which = getenv("FS_DEBUG_NAN");      // (read per call: a test switches it on and off)
+    if (!which || !*which) return 0;
+    auto fill = [&](DevBuf &b) -> hipError_t {
+        return b.p ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.p), 0x7fc00000, b.cap / 4, ctx->stream) : hipSuccess;
+    };
+    for (const char *c = which; *c; ++c) {
+        if (*c == 'q') { FS_HIP(fill(ctx->qa)); FS_HIP(fill(ctx->qb)); }
+        if (*c == 'a') FS_HIP(fill(ctx->featA));
+        if (*c == 'b') FS_HIP(fill(ctx->featB));
+        if (*c == 's') FS_HIP(fill(ctx->smoothed));
+        if (*c == 'r') FS_HIP(fill(ctx->raw));
+        if (*c == 't' && ctx->tile_recs.p) FS_HIP(hipMemsetAsync(ctx->tile_recs.p, 0xff, ctx->tile_recs.cap, ctx->stream));   // tile records: -1
+    }
+    return 0;
+}
+
 // get_angle_arrays (image_processing_models_GPU.py:137-149) and the lateral pixel
 // size factors |tan[i-1] - tan[i+1]| of find_surfaces.py:237-238, on the host in
 // fp32 so that the tables are the same numbers a CPU evaluation would use.
@@ -1023,6 +1045,7 @@ int find_surfaces_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t
     const bool fused_crf = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;     // as run_crf_batch decides
     // One frame per call: the updates go out before the label count has come back (launch_crf_speculative).
     const bool speculate = ctx->speculate && n == 1 && fused_crf;
+    if (debug_nan_fill(ctx)) return -1;
     {
         ScopedTimer t(ctx, G_STENCIL);
         // (the colour half of the fused CRF update's feature records is written on the way: it needs the same depth)

@@ -371,6 +371,9 @@ __device__ __forceinline__ void build_channel_list(int *s_list, const int32_t *t
                 labs[ce++] = rep;
             }
             labs[ce++] = S - 1;
+            // the slots that fill up the last group of four get a label no pixel carries: what the record held behind its
+            // labels (another tile's, another call's) must not pass for a pixel's own label where the groups are walked
+            for (int pad = ce; pad < ((ce + 3) & ~3); ++pad) labs[pad] = -2;
             m[0] |= 1;
             m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
             s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;

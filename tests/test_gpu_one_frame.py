@@ -200,3 +200,26 @@ def test_results_do_not_depend_on_what_freed_memory_held():
     with Context(H, W, max_batch=3) as after:
         _same(after.find_surfaces_batch(*one), ref_one, "one frame")
         _same(after.find_surfaces_batch(d, c), ref_batch, "three frames")
+
+
+def test_results_do_not_depend_on_what_the_work_buffers_held():
+    """FS_DEBUG_NAN fills the float work buffers with NaN and the CRF's tile records with -1 in front of every call: a
+    kernel that used a value this call has not written would show it.  (A tile's channel list is walked in groups of
+    four; the slots that fill up the last group once compared whatever the record held behind its labels with the
+    pixel's own label, and a match shifted the softmax's maximum: labels flipped at near-ties, depending on what earlier
+    calls had left there.)"""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = 480, 640
+    d, c = make_batch([91, 92, 93], H, W)
+    with Context(H, W, max_batch=3) as ctx:
+        ref_batch = ctx.find_surfaces_batch(d, c)
+        ref_one = [ctx.find_surfaces_batch(d[i], c[i]) for i in range(3)]
+        os.environ["FS_DEBUG_NAN"] = "qabsrt"
+        try:
+            for _ in range(2):
+                _same(ctx.find_surfaces_batch(d, c), ref_batch, "three frames")
+                for i in range(3):
+                    _same(ctx.find_surfaces_batch(d[i], c[i]), ref_one[i], f"frame {i} alone")
+        finally:
+            del os.environ["FS_DEBUG_NAN"]
