@@ -183,8 +183,8 @@ int set_device(fs_ctx *ctx)
 
 // FS_DEBUG_NAN=<letters>: float work buffers named by the letters are filled with NaN in front of every find_surfaces
 // call (q: both sets of probability planes, a / b: the two halves of the feature records, s: smoothed depth, r: raw
-// angles; t: the tile records of the CRF update, as -1), so that a kernel that reads a value nobody wrote in this call
-// shows up in the results.
+// angles; t: the tile records of the CRF update, as -1; p c n k u o m v e l: one integer work buffer each, as 1), so that
+// a kernel that reads a value nobody wrote in this call shows up in the results.
 int debug_nan_fill(fs_ctx *ctx)
 {
     const char *which = getenv("FS_DEBUG_NAN");      // (read per call: a test switches it on and off)
@@ -198,6 +198,16 @@ int debug_nan_fill(fs_ctx *ctx)
         if (*c == 'b') FS_HIP(fill(ctx->featB));
         if (*c == 's') FS_HIP(fill(ctx->smoothed));
         if (*c == 'r') FS_HIP(fill(ctx->raw));
+        // integer work buffers, as the in-range value 1 (the components' parents, sizes, ranks and block sums, the
+        // undecided-pixel lists, the label counts, mask, curvature decisions, edges and the int32 patch labels)
+        DevBuf *ints[] = {&ctx->cc_parent, &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->curv_todo, &ctx->counts,
+                          &ctx->mask, &ctx->curv, &ctx->edges, &ctx->patches32};
+        const char *names = "pcnkuomvel";
+        for (int i = 0; names[i]; ++i)
+            if (*c == names[i] && ints[i]->p) {
+                FS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ints[i]->p), 1, ints[i]->cap / 4, ctx->stream));
+                if (names[i] == 'u') ctx->todo_clean = false;       // (the lists' counters are cleared again by the call)
+            }
         if (*c == 't' && ctx->tile_recs.p) FS_HIP(hipMemsetAsync(ctx->tile_recs.p, 0xff, ctx->tile_recs.cap, ctx->stream));   // tile records: -1
     }
     return 0;
