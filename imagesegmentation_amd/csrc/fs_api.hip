@@ -183,7 +183,8 @@ int set_device(fs_ctx *ctx)
 
 // FS_DEBUG_NAN=<letters>: float work buffers named by the letters are filled with NaN in front of every find_surfaces
 // call (q: both sets of probability planes, a / b: the two halves of the feature records, s: smoothed depth, r: raw
-// angles; t: the tile records of the CRF update, as -1; p c n k u o m v e l: one integer work buffer each, as 1), so that
+// angles; t: the tile records of the CRF update, as -1; p c n k u o m v e l: one integer work buffer each, as 1; w, read by the statistics stage: its work
+// arrays, as 1), so that
 // a kernel that reads a value nobody wrote in this call shows up in the results.
 int debug_nan_fill(fs_ctx *ctx)
 {
@@ -1368,6 +1369,11 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
     w.ext_all = reinterpret_cast<uint32_t *>(ext);
     w.ext_words = tot.ext / 4;
     w.err = d_err;
+    if (const char *dbg = getenv("FS_DEBUG_NAN"); dbg && std::strchr(dbg, 'w')) {
+        // the statistics stage's work arrays and the part of its scratch that no memset prepares, as 32-bit ones
+        FS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->st_work.p), 1, ctx->st_work.cap / 4, ctx->stream));
+        FS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(plain), 1, tot.plain / 4, ctx->stream));
+    }
     FS_HIP(hipMemsetAsync(zero, 0, tot.zero, ctx->stream));
     FS_HIP(hipMemsetAsync(ones, 0xff, tot.ones, ctx->stream));
     FS_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
