@@ -41,6 +41,8 @@ SIGNATURES = {
     "fs_crf_step": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fs_crf_step_lr": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "fs_find_surfaces_batch": (_i, [_vp, _i] + [_vp] * 9),
+    "fs_find_surfaces_trace": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_synchronize": (_i, [_vp]),
     "fs_host_alloc": (_vp, [_c.c_size_t]),
     "fs_host_free": (None, [_vp]),
     "fs_find_surfaces_batch_dev": (_i, [_vp, _i] + [_vp] * 9),
@@ -101,7 +103,7 @@ def lr_parameters():
 _POOL = {}                  # block size -> addresses of free blocks
 _POOL_BYTES = 0
 _POOL_LIMIT = 1 << 30
-_POOL_LOCK = threading.Lock()
+_POOL_LOCK = threading.RLock()      # re-entrant: a collection inside a locked section may finalise another block
 
 
 def _block_size(nbytes):
@@ -346,11 +348,8 @@ class Context:
                                                               d_num_labels))
 
     def synchronize(self):
-        """Wait for the context's stream through the HIP runtime the library is linked against."""
-        hip = ctypes.CDLL("libamdhip64.so.7")
-        hip.hipStreamSynchronize.argtypes = [_vp]
-        if hip.hipStreamSynchronize(self.stream()) != 0:
-            raise RuntimeError("hipStreamSynchronize failed")
+        """Wait for the context's stream (fs_synchronize: the library's own HIP runtime does the waiting)."""
+        self._check(self._lib.fs_synchronize(self._h))
 
     def crf_step(self, unary, Q, f1, f2, f3, val, want_potentials=False):
         unary = _arr(unary, np.float32)
@@ -409,6 +408,18 @@ class Context:
             out = {k: v[0] for k, v in out.items()}
             out["num_surfaces"] = int(out["num_surfaces"])
         return out
+
+    def find_surfaces_trace(self, depth, rgb):
+        """fs_find_surfaces_trace for one frame: the stage with the diagnostic builds of the mean-field updates ->
+        dict with potentials and probabilities float32 [3, S, H, W] (zero where the frame has no depth), patches,
+        surfaces, num_surfaces."""
+        d, c = _arr(depth, np.uint16, (self.H, self.W)), _arr(rgb, np.uint8, (self.H, self.W, 3))
+        S = int(self.find_surfaces_batch(d, c)["num_surfaces"]) + 1
+        pot, q = np.empty((3, S, self.H, self.W), np.float32), np.empty((3, S, self.H, self.W), np.float32)
+        pat, sur = np.empty((self.H, self.W), np.int64), np.empty((self.H, self.W), np.int64)
+        ns = np.zeros(1, np.int32)
+        self._check(self._lib.fs_find_surfaces_trace(self._h, _ptr(d), _ptr(c), S, _ptr(pot), _ptr(q), _ptr(pat), _ptr(sur), _ptr(ns)))
+        return {"potentials": pot, "probabilities": q, "patches": pat, "surfaces": sur, "num_surfaces": int(ns[0])}
 
     def find_surfaces_batch_dev(self, n, d_depth, d_rgb, d_angles=None, d_vectors=None, d_points=None, d_patches=None,
                                 d_edges=None, d_surfaces=None):

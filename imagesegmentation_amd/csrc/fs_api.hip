@@ -68,6 +68,10 @@ struct fs_ctx {
     DevBuf publish_seq;                            // device word: one-frame calls so far (the kernels count)
     unsigned publish_expected = 0;                 // ... as the host counts them
     DevBuf spec_descs;
+    // fs_find_surfaces_trace: while trace_cap != 0 the updates run as their diagnostic builds and leave the softmax
+    // arguments and the probabilities of every update in trace_buf ([update][2][S][N] floats), S <= trace_cap
+    DevBuf trace_buf;
+    int trace_cap = 0, trace_S = 0;
     DevBuf apply_stats;                            // fs_apply_crf: per-frame label maxima and flags
     HostBuf apply_stats_host;
     HostBuf spec_descs_host;
@@ -485,6 +489,16 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     if (!fused && ensure_sim(ctx, N, W, gmax, &sim0, &sim_stride)) return -1;
     FS_HIP(ctx->qa.ensure(qmax * sizeof(float)));
     FS_HIP(ctx->qb.ensure(qmax * sizeof(float)));
+    const bool trace = ctx->trace_cap != 0;
+    if (trace) {
+        if (n != 1 || !fused) return ctx->fail("the diagnostic updates take one frame and the fused kernels");
+        ctx->trace_S = S[0];
+        if (S[0] > ctx->trace_cap)
+            return ctx->fail("the frame has " + std::to_string(S[0]) + " label channels, the caller's arrays hold " + std::to_string(ctx->trace_cap));
+        const size_t bytes = (size_t)iterations * 2 * S[0] * N * sizeof(float);
+        FS_HIP(ctx->trace_buf.ensure(bytes));
+        FS_HIP(hipMemsetAsync(ctx->trace_buf.p, 0, bytes, ctx->stream));
+    }
 
     // descriptors: [group][iteration][frames of the group ordered by channel class]
     // page-locked, so that the upload is a plain DMA transfer; the previous upload must have left it
@@ -526,7 +540,8 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                 d.featB = fused ? ctx->featB.as<float2>() + (size_t)fi * N : nullptr;
                 d.Qin = qin + qoff[f];
                 d.Qout = last ? nullptr : qout + qoff[f];
-                d.potentials = nullptr;
+                d.potentials = trace ? ctx->trace_buf.as<float>() + (size_t)(2 * it) * S[0] * N : nullptr;
+                d.trace_q = trace ? ctx->trace_buf.as<float>() + (size_t)(2 * it + 1) * S[0] * N : nullptr;
                 d.unary = nullptr;
                 d.patches = d_labels32 + (size_t)fi * N;
                 d.depth_raw = d_depth + (size_t)fi * N;
@@ -572,7 +587,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                     queue_slot = 0;
                 }
                 unsigned *queue = ctx->crf_queue.as<unsigned>() + (fused ? queue_slot++ : 0) * (kCrfQueueBytes / sizeof(unsigned));
-                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream)
+                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, trace)
                                      : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }
@@ -694,7 +709,7 @@ void fs_destroy(fs_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->spec_descs, &ctx->apply_stats, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
+    DevBuf *bufs[] = {&ctx->trace_buf, &ctx->spec_descs, &ctx->apply_stats, &ctx->publish_seq, &ctx->tanx, &ctx->tany, &ctx->ax, &ctx->ay, &ctx->pos_terms, &ctx->wtab, &ctx->depth16, &ctx->rgb8, &ctx->depthf,
                       &ctx->smoothed, &ctx->points, &ctx->normals, &ctx->raw, &ctx->angles, &ctx->curv, &ctx->scores,
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin,
@@ -812,6 +827,14 @@ int fs_use_own_stream(fs_ctx *ctx)
     if (set_device(ctx)) return -1;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) (void)hipGetLastError();
     ctx->stream = ctx->own_stream;
+    return 0;
+}
+
+int fs_synchronize(fs_ctx *ctx)
+{
+    if (!ctx) return -1;
+    if (set_device(ctx)) return -1;
+    FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -1055,7 +1078,7 @@ int find_surfaces_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t
     int64_t *surfaces = d_surfaces ? d_surfaces : ctx->surfaces64.as<int64_t>();
     const bool fused_crf = !ctx->use_planes && crf_fused_tile_height(ctx->r) != 0;     // as run_crf_batch decides
     // One frame per call: the updates go out before the label count has come back (launch_crf_speculative).
-    const bool speculate = ctx->speculate && n == 1 && fused_crf;
+    const bool speculate = ctx->speculate && n == 1 && fused_crf && ctx->trace_cap == 0;
     if (debug_nan_fill(ctx)) return -1;
     {
         ScopedTimer t(ctx, G_STENCIL);
@@ -1208,6 +1231,37 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         if (surfaces) FS_HIP(hipMemcpyAsync(surfaces + o, ctx->surfaces64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
     }
     FS_HIP(hipStreamSynchronize(ctx->out_stream));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int fs_find_surfaces_trace(fs_ctx *ctx, const uint16_t *depth, const uint8_t *rgb, int max_channels, float *potentials,
+                           float *probabilities, int64_t *patches, int64_t *surfaces, int32_t *num_surfaces)
+{
+    if (check_batch(ctx, 1)) return -1;
+    if (!depth || !rgb || max_channels < 2) return ctx->fail("fs_find_surfaces_trace: depth, rgb and max_channels >= 2 are required");
+    const size_t N = ctx->N();
+    FS_HIP(ctx->depth16.ensure((size_t)ctx->max_batch * N * 2));
+    FS_HIP(ctx->rgb8.ensure((size_t)ctx->max_batch * N * 3));
+    FS_HIP(hipStreamSynchronize(ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->depth16.p, depth, N * 2, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(hipMemcpyAsync(ctx->rgb8.p, rgb, N * 3, hipMemcpyHostToDevice, ctx->stream));
+    ctx->trace_cap = max_channels;
+    ctx->trace_S = 0;
+    int32_t ns = 0;
+    const int rc = find_surfaces_dev(ctx, 1, ctx->depth16.as<uint16_t>(), ctx->rgb8.as<uint8_t>(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, &ns, StageHook());
+    ctx->trace_cap = 0;
+    if (num_surfaces) *num_surfaces = ns;
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return -1; }
+    const size_t plane_set = (size_t)ctx->trace_S * N;
+    for (int it = 0; it < 3; ++it) {
+        const float *src = ctx->trace_buf.as<float>() + (size_t)(2 * it) * plane_set;
+        if (potentials) FS_HIP(hipMemcpyAsync(potentials + it * plane_set, src, plane_set * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (probabilities) FS_HIP(hipMemcpyAsync(probabilities + it * plane_set, src + plane_set, plane_set * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (patches) FS_HIP(hipMemcpyAsync(patches, ctx->patches64.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (surfaces) FS_HIP(hipMemcpyAsync(surfaces, ctx->surfaces64.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

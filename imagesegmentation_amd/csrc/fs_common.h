@@ -190,6 +190,7 @@ struct CrfFrameDesc {            // one frame of a batched launch (device-reside
     const float *Qin;            // label planes [S][Hi*Wi]
     float *Qout;                 // label planes [S][oh*ow] or null
     float *potentials;           // label planes [S][oh*ow] or null
+    float *trace_q;              // fused update, diagnostic kernels only: all S planes of the new probabilities, or null
     const float *unary;          // explicit unary planes [S][oh*ow] or null (then synthesised from patches)
     const int32_t *patches;      // [Hi*Wi] or null
     const uint16_t *depth_raw;   // [Hi*Wi] or null: invalid-depth override (and depth feature of the fused update)
@@ -265,7 +266,10 @@ float crf_colour_feature_scale(const CrfParams &P);
 // that share it must be ordered on one stream).
 constexpr size_t kCrfQueueStride = 128, kCrfQueueBytes = 8 * kCrfQueueStride;
 constexpr int kCrfQueueSlots = 64;
+// trace: the diagnostic build of the kernel, which also fills descs[].potentials and descs[].trace_q (Gaussian similarity
+// with uniform window constants only)
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
-                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st);
+                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st,
+                                 bool trace = false);
 
 }  // namespace fs

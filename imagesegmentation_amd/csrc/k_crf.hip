@@ -766,7 +766,7 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
 }
 
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
-                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st)
+                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st, bool trace)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
@@ -783,7 +783,8 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     K.uw[0] = (float)-std::log2((double)P.w1); K.uw[1] = (float)-std::log2((double)P.w2); K.uw[2] = (float)-std::log2((double)P.w3);
     K.uw[3] = 0.0f;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
-    const FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st};
+    const FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st, trace};
+    if (trace) return uniform ? launch_fused_trace(channel_class, L) : hipErrorInvalidValue;
     if (P.mode == 1) return launch_roll_table(2, channel_class, L);
     if (!uniform) return launch_roll_table(1, channel_class, L);
     // r = 7 keeps the tile with its whole halo in LDS (no step barriers, no half-idle first and last window row); a

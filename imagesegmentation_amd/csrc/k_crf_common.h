@@ -34,6 +34,7 @@ struct FusedLaunch {
     int first, last;
     unsigned *queue;
     hipStream_t st;
+    bool trace = false;      // the diagnostic kernels, which also write CrfFrameDesc::potentials and trace_q
 };
 // Instance files (k_crf_fused_*.hip): each compiles the kernel variants it names and returns
 // hipErrorInvalidValue for a combination it does not carry.
@@ -42,6 +43,8 @@ struct FusedLaunch {
 hipError_t launch_fused_r7_uniform(int channel_class, const FusedLaunch &L);      // static tile + halo in LDS, r = 7
 hipError_t launch_roll_uniform(int channel_class, const FusedLaunch &L);          // rolling window, variant 0, any radius
 hipError_t launch_roll_table(int variant, int channel_class, const FusedLaunch &L);   // rolling window, variants 1 and 2
+// the same kernels built with their diagnostic outputs (variant 0 at any radius; k_crf_trace.hip)
+hipError_t launch_fused_trace(int channel_class, const FusedLaunch &L);
 
 constexpr int FTW = 32;                       // tile width of the fused kernel
 
@@ -99,15 +102,44 @@ struct LdsAllowance {
     }
 };
 
+// Diagnostic build only: sign * v[c] of every channel slot written to the plane of the slot's label, for the lane's two
+// pixels where they have a depth, and the representative's value to the plane of every label the tile does not list
+// (s_list[REC_MASK ..] has the bits of the listed labels, of 0 and of S - 1).
+template <int NC>
+__device__ __forceinline__ void trace_planes(const f2 (&v)[NC], float sign, float *planes, const int *s_list, int S, size_t No,
+                                             const unsigned (&p)[2], const bool (&ok)[2], const bool (&valid)[2])
+{
+    const int CE = s_list[0], rep_pos = s_list[2];
+    f2 rep = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < CE) {
+            const int lab = s_list[REC_LAB + c];
+            const f2 t = v[c] * f2{sign, sign};
+            if (c == rep_pos) rep = t;
+            if (ok[0] && valid[0]) planes[(size_t)lab * No + p[0]] = t.x;
+            if (ok[1] && valid[1]) planes[(size_t)lab * No + p[1]] = t.y;
+        }
+    }
+    if (rep_pos < 0) return;
+    for (int l = 1; l < S - 1; ++l) {
+        if ((unsigned)s_list[REC_MASK + (l >> 5)] >> (l & 31) & 1u) continue;
+        if (ok[0] && valid[0]) planes[(size_t)l * No + p[0]] = rep.x;
+        if (ok[1] && valid[1]) planes[(size_t)l * No + p[1]] = rep.y;
+    }
+}
+
 // Potts compatibility, softmax and overrides of the fused update for the two vertically adjacent pixels a lane owns
-// (compact planes, synthesised unary, no potentials output).  m[c] = messages of channel slot c as a packed pair
+// (compact planes, synthesised unary).  m[c] = messages of channel slot c as a packed pair
 // (pixel 0, pixel 1), so the arithmetic is v_pk_*_f32 like the window walk.  The work follows the tile's channel
 // count: slots are visited in groups of four behind one uniform test per group, and what depends on a slot's role
 // comes from s_tab[c] = (multiplicity, evidence, unary, -): multiplicity 1 for a listed label, n_rest for the
 // representative, 0 for an unused slot of the last group; evidence of the constant "unassigned" input at the last
 // channel (find_surfaces.py:356-357, 451-452); unary potential of the slot's label at a pixel that does not belong to
 // it: 10 for label 0, 1 otherwise (:459-472), +inf for an unused slot (probability 0).
-template <int NC>
+// TRACE (diagnostic builds): d.potentials and d.trace_q, where not null, receive the softmax argument and the new
+// probabilities of all S labels.
+template <int NC, bool TRACE = false>
 __device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_list, const float4 *s_tab, const CrfFrameDesc &d, int S,
                                                     size_t No, const unsigned (&p)[2], const int (&own)[2], const bool (&ok)[2],
                                                     const bool (&valid)[2], float weight, int last)
@@ -151,29 +183,9 @@ __device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_li
             }
         }
     }
-    if (last) {
-        // Only the label is wanted (:531-532).  The softmax is monotone, so its first maximum is the first maximum of
-        // its argument, except where two arguments differ by so little that their exponentials round to the same
-        // float: such labels are numerically tied and the choice between them carries no information.
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!ok[i]) continue;
-            int best = 0;
-            float bestv = -INFINITY;
-            if (valid[i]) {                                              // Q[depth == 0] = 0: argmax of zeros is label 0
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    if (c < CE) {
-                        const int lab = s_list[REC_LAB + c];
-                        const float v = i == 0 ? m[c].x : m[c].y;
-                        if (v > bestv || (v == bestv && lab < best)) { bestv = v; best = lab; }
-                    }
-                }
-            }
-            d.surfaces[p[i]] = best == S - 1 ? 0 : best;
-        }
-        return;
-    }
+    // Diagnostic build only: the softmax argument unary + weight * compatibility of every one of the S labels, as label
+    // planes like Q; a label the tile does not list carries the representative's value.
+    if (TRACE && d.potentials) trace_planes<NC>(m, -1.0f, d.potentials, s_list, S, No, p, ok, valid);
     f2 den = f2{0.0f, 0.0f};
     const f2 mx = f2{mx0, mx1};
 #pragma unroll
@@ -188,17 +200,45 @@ __device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_li
             }
         }
     }
+    if (last) {
+        // Only the label is wanted: the first maximum of the float32 probabilities (:531-532).  Labels whose arguments
+        // lie so close to the largest one that their quotients round to the same float are tied there, and the lowest
+        // of them wins; taking the maximum of the arguments instead would let the last bit of an argument decide.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!ok[i]) continue;
+            int best = 0;
+            float bestv = -1.0f;
+            const float deni = i == 0 ? den.x : den.y;
+            if (valid[i]) {                                              // Q[depth == 0] = 0: argmax of zeros is label 0
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (c < CE) {
+                        const int lab = s_list[REC_LAB + c];
+                        const float v = (i == 0 ? m[c].x : m[c].y) / deni;
+                        if (TRACE) { if (i == 0) m[c].x = v; else m[c].y = v; }
+                        if (v > bestv || (v == bestv && lab < best)) { bestv = v; best = lab; }
+                    }
+                }
+            }
+            d.surfaces[p[i]] = best == S - 1 ? 0 : best;
+        }
+        if (TRACE && d.trace_q) trace_planes<NC>(m, 1.0f, d.trace_q, s_list, S, No, p, ok, valid);
+        return;
+    }
     const f2 inv_den = f2{1.0f / den.x, 1.0f / den.y};
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < CE) {
             const int lab = s_list[REC_LAB + c];
             const f2 q = m[c] * inv_den;
+            if (TRACE) m[c] = q;
             const float ov = lab == 0 ? 0.0f : pv;                       // Q[depth == 0] = prob, :520-525
             if (ok[0]) d.Qout[(size_t)lab * No + p[0]] = valid[0] ? q.x : ov;
             if (ok[1]) d.Qout[(size_t)lab * No + p[1]] = valid[1] ? q.y : ov;
         }
     }
+    if (TRACE && d.trace_q) trace_planes<NC>(m, 1.0f, d.trace_q, s_list, S, No, p, ok, valid);
 }
 
 }  // namespace

@@ -199,7 +199,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
 }
 
-template <int R, int TH, int NCH, int MODE, bool UNIFORM>
+template <int R, int TH, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last,
                                                              int nframes, unsigned *__restrict__ queue)
@@ -495,17 +495,17 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         f2 m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = f2{acc[c / CH][0][c % CH], acc[c / CH][1][c % CH]};     // the epilogue works on pixel pairs
-        finish_pair_compact<NCH * CH>(m, s_list, s_tab, d, S, Ni, p, own, ok, valid, weight, last);
+        finish_pair_compact<NCH * CH, TRACE>(m, s_list, s_tab, d, S, Ni, p, own, ok, valid, weight, last);
     }
     if (threadIdx.x == 0) s_ticket = next_ticket;     // every lane read the current ticket several barriers ago
     __syncthreads();                                  // the next tile reuses the LDS
   }
 }
-template <int R, int TH, int NCH, int MODE, bool UNIFORM = false>
+template <int R, int TH, int NCH, int MODE, bool UNIFORM = false, bool TRACE = false>
 hipError_t launch_fused_t(const FusedLaunch &L)
 {
     static LdsAllowance allowed;
-    auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE, UNIFORM>;
+    auto kern = crf_iter_fused_kernel<R, TH, NCH, MODE, UNIFORM, TRACE>;
     const CrfGeom &g = L.g;
     const size_t lds = (size_t)(FTW + 2 * g.r) * (TH + 2 * g.r) * (3 * sizeof(float4) + sizeof(float2));
     const size_t lds_static = sizeof(int) * (TILE_REC + 15 * NCH * 8 + 15 * MASK_WORDS + 2 * NCH * 8 + 4);

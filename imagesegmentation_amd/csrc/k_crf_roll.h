@@ -148,7 +148,7 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
 template <int R>
 constexpr int roll_blocks_per_cu() { return (R > 0 && (FTW + 2 * R) * RING * 56 + 6 * 1024 <= 160 * 1024 / 3) ? 3 : 2; }
 
-template <int R, int NCH, int MODE, bool UNIFORM>
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
 __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
                                                             int nframes, unsigned *__restrict__ queue)
@@ -416,18 +416,18 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         f2 m[NCH * CH];
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) m[c] = acc[c / CH][c % CH];
-        finish_pair_compact<NCH * CH>(m, s_list, s_tab, d, S, Ni, p, own, ok, valid, weight, last);
+        finish_pair_compact<NCH * CH, TRACE>(m, s_list, s_tab, d, S, Ni, p, own, ok, valid, weight, last);
     }
     if (threadIdx.x == 0) s_ticket = next_ticket;     // every lane read the current ticket several barriers ago
     __syncthreads();                                  // the next tile reuses the LDS
   }
 }
 
-template <int R, int NCH, int MODE, bool UNIFORM>
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
 hipError_t launch_roll_t(const FusedLaunch &L)
 {
     static LdsAllowance allowed;
-    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM>;
+    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM, TRACE>;
     const CrfGeom &g = L.g;
     if (R && g.r != R) return hipErrorInvalidValue;
     const size_t lds = (size_t)(FTW + 2 * g.r) * RING * (3 * sizeof(float4) + sizeof(float2));

@@ -139,6 +139,18 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                            float *vectors, float *points, int64_t *patches, int32_t *edges, int64_t *surfaces,
                            int32_t *num_surfaces);
 
+/* The same stage for one frame with the mean-field updates run as diagnostic builds of the production kernels (same
+ * arithmetic, instruction for instruction, plus stores): the three calls of conv_crf_Gauss(...).predict at
+ * find_surfaces.py:517-529 leave their softmax argument unary + weight * compatibility (:361) in
+ * potentials [3][S][H][W] and their result (:363, before the Q[depth == 0] assignments of :520-530) in
+ * probabilities [3][S][H][W], label planes, S = num_surfaces + 1, written at pixels with a depth and zero elsewhere.
+ * max_channels: the S the caller's arrays were sized for; a frame with more fails (num_surfaces is set all the same, so
+ * the caller can size the arrays and call again).  Host pointers, any output may be NULL; Gaussian similarity with the
+ * window constants of the trained parameters only.  This is how the tests hold the production kernels' floating-point
+ * results against a CPU evaluation; it is several times slower than fs_find_surfaces_batch. */
+int fs_find_surfaces_trace(fs_ctx *ctx, const uint16_t *depth, const uint8_t *rgb, int max_channels, float *potentials,
+                           float *probabilities, int64_t *patches, int64_t *surfaces, int32_t *num_surfaces);
+
 /* Page-locked host memory for the arrays passed to fs_find_surfaces_batch: with it the uploads and downloads
  * are DMA transfers that overlap the kernels of neighbouring chunks (several times the throughput of
  * pageable arrays).  No counterpart in the reference.  fs_host_alloc returns NULL on failure. */
@@ -153,6 +165,10 @@ void fs_host_free(void *p);
 int fs_find_surfaces_batch_dev(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_rgb, float *d_angles,
                                float *d_vectors, float *d_points, int64_t *d_patches, int32_t *d_edges,
                                int64_t *d_surfaces, int32_t *num_surfaces);
+
+/* Waits until everything the context has enqueued on its stream is done (the calls that take device pointers return
+ * before their kernels have run).  No counterpart in the reference, whose calls are synchronous. */
+int fs_synchronize(fs_ctx *ctx);
 
 /* post_processing.apply_CRF (post_processing.py:4-19): one mean-field pass with
  * `labels` (int64 [n][H][W], e.g. final_surfaces) in the role of the patches, then
