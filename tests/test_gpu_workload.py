@@ -1,6 +1,7 @@
 """The whole headline workload (all 111 OSD frames in one batch, the configuration bench.py times) through
 the C ABI, against the committed oracle results of tests/golden/osd_all.npz
 (tests/golden/make_golden_osd_all.py): the reference's main.find_surfaces_for_dataset (main.py:25-26)."""
+import json
 import os
 import zlib
 
@@ -12,6 +13,9 @@ from conftest import osd_frame
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "osd_all.npz")
+# per-frame number of labels that differed from the oracle's when the fixture was made on the GPU
+# (tests/golden/make_osd_label_diffs.py): 11 953 of 34 million, at most 290 in a frame, every one at a numerical tie
+LABEL_DIFFS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "osd_label_diffs.json")
 
 
 def test_all_osd_frames_in_one_batch():
@@ -24,7 +28,9 @@ def test_all_osd_frames_in_one_batch():
     with Context(480, 640, max_batch=n) as ctx:
         got = ctx.find_surfaces_batch(d, c)
     assert np.array_equal(got["num_surfaces"], g["num_surfaces"])
-    worst = 1.0
+    with open(LABEL_DIFFS) as f:
+        recorded = json.load(f)["label_differences"]
+    worst, total = 1.0, 0
     for i in range(n):
         # integer stages: bit-exact
         assert zlib.crc32(np.ascontiguousarray(got["patches"][i].astype(np.int32)).tobytes()) == g["crc_patches"][i], i
@@ -34,7 +40,12 @@ def test_all_osd_frames_in_one_batch():
         if dis.any():
             tie = np.unpackbits(g["near_tie"][i])[:dis.size].reshape(dis.shape).astype(bool)
             assert not (dis & ~tie).any(), f"frame {i}: {int((dis & ~tie).sum())} label differences that are not ties"
+        # ... and no more of them than recorded: the kernels are deterministic, so a frame that shows more has changed
+        # its arithmetic, if only inside the ties (stale operands, another summation order)
+        assert int(dis.sum()) <= recorded[i], f"frame {i}: {int(dis.sum())} label differences, {recorded[i]} recorded"
+        total += int(dis.sum())
         worst = min(worst, 1.0 - dis.mean())
+    print(f"label differences: {total} in {n} frames ({sum(recorded)} recorded), worst frame agreement {worst:.5f}")
     assert worst >= 0.999, worst
 
 
