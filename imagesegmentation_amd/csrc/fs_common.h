@@ -39,10 +39,18 @@ struct DevBuf {
         // A new buffer starts as zeros, whatever the allocator hands out (memory that another context of the process
         // has freed keeps its contents): a value that a kernel multiplies by a weight of exactly zero -- the
         // probabilities of a neighbour without depth, say -- must not be the NaN that old integer data reads as.
-        // (FS_DEBUG_NEW_BUFFERS_AS_ONES=1 for testing: 32-bit words of value 1 instead, in range as an index, a label or a
-        // count wherever a kernel might take one from a word it has not written)
-        static const bool ones = [] { const char *v = getenv("FS_DEBUG_NEW_BUFFERS_AS_ONES"); return v && v[0] == '1'; }();
-        if (e == hipSuccess) e = ones ? hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 1, want / 4) : hipMemset(p, 0, want);
+        // (FS_DEBUG_NEW_BUFFERS_AS_ONES for testing: =1 fills with 32-bit words of value 1 instead, in range as an index, a
+        // label or a count wherever a kernel might take one from a word it has not written; =2 with all-ones bytes, which
+        // read as -1, as NaN and as an address far outside every array: a kernel that takes an index from a word nobody
+        // wrote faults, and one that uses such a float shows NaN in its results)
+        static const int fill = [] {
+            const char *v = getenv("FS_DEBUG_NEW_BUFFERS_AS_ONES");
+            const int f = v && v[0] >= '1' && v[0] <= '2' ? v[0] - '0' : 0;
+            if (f) fprintf(stderr, "fs_hip: FS_DEBUG_NEW_BUFFERS_AS_ONES=%d, new device buffers start as %s\n", f, f == 1 ? "32-bit ones" : "all-ones bytes");
+            return f;
+        }();
+        if (e == hipSuccess)
+            e = fill == 1 ? hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), 1, want / 4) : hipMemset(p, fill == 2 ? 0xff : 0, want);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (done before a kernel on another stream writes there)
         return e;
     }
