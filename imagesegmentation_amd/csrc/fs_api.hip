@@ -464,6 +464,10 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     const size_t rec_stride = (size_t)tiles_x * tiles_y * crf_tile_rec_ints();
     for (int i = 0; i < n; ++i)
         if (S[i] > kMaxLabels) return ctx->fail("frame has " + std::to_string(S[i]) + " label channels; at most " + std::to_string(kMaxLabels) + " are supported");
+    // the update kernels address a frame's probability planes with 32-bit element offsets
+    for (int i = 0; i < n; ++i)
+        if ((uint64_t)S[i] * N >= ((uint64_t)1 << 32))
+            return ctx->fail("a frame of " + std::to_string(N) + " pixels with " + std::to_string(S[i]) + " label channels exceeds 2^32 probabilities");
     // groups: consecutive frames, limited in number and in the size of their Q planes
     std::vector<int> gstart{0};
     size_t qmax = 0;
@@ -613,6 +617,7 @@ int launch_crf_speculative(fs_ctx *ctx, const uint16_t *d_depth, const int32_t *
     FS_HIP(ctx->qa.ensure((size_t)kSpecLabels * N * sizeof(float)));
     FS_HIP(ctx->qb.ensure((size_t)kSpecLabels * N * sizeof(float)));
     ctx->spec_cap = (int)std::min<size_t>(std::min(ctx->qa.cap, ctx->qb.cap) / (N * sizeof(float)), (size_t)kMaxLabels);
+    ctx->spec_cap = (int)std::min<uint64_t>((uint64_t)ctx->spec_cap, (((uint64_t)1 << 32) - 1) / N);     // 32-bit plane offsets in the kernels
     std::vector<CrfFrameDesc> want((size_t)iterations);
     for (int it = 0; it < iterations; ++it) {
         const bool last = it == iterations - 1;

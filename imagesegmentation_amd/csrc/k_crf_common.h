@@ -5,9 +5,17 @@
 #include <mutex>
 
 #include "fs_common.h"
-// Timing experiments only (never defined in the product build): -DFS_SKIPMAIN=1 drops the window walk of the
-// fused update, -DFS_SKIPQ=1 the staging of Q, -DFS_SKIPFIN=1 the epilogue.  Builds with parts switched off,
-// run under the SQ counters (tools/pmc_variant.sh), tell how the vector instructions split over the phases.
+// Timing experiments only (tools/build_variant.sh compiles the r = 7 instance file with one of them set and
+// tools/run_variants.sh times the builds side by side; the product build defines none): FS_SKIPMAIN=1 drops the window
+// walk of the fused update, FS_SKIPSIM=1 only the similarity's arithmetic inside it, FS_SKIPQ=1 the staging of Q,
+// FS_SKIPFIN=1 the epilogue; FS_DEPTH_SERIES=0 evaluates the relative depth difference with a reciprocal per neighbour
+// instead of the series (see fused_accumulate).
+#ifndef FS_DEPTH_SERIES
+#define FS_DEPTH_SERIES 1
+#endif
+#ifndef FS_SKIPSIM
+#define FS_SKIPSIM 0
+#endif
 #ifndef FS_SKIPQ
 #define FS_SKIPQ 0
 #endif
@@ -52,6 +60,31 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));      // packed pair: arithmetic lowers to v_pk_*_f32
 typedef __attribute__((address_space(1))) float gfloat;   // pointer known to be global: saddr + 32-bit offset loads
+// A pointer that came out of a descriptor in memory is generic to the compiler, and loads through it are flat loads,
+// which count as LDS operations as well: every wait for an LDS read then also waits for the loads in flight.  The
+// arrays of a descriptor are device memory, so the kernels say so where they use them.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *global_ptr(const T *p)
+{
+    return (const __attribute__((address_space(1))) T *)p;
+}
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *global_ptr(T *p)
+{
+    return (__attribute__((address_space(1))) T *)p;
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 global_load4(const float4 *p, unsigned i)
+{
+    const f4v v = ((const __attribute__((address_space(1))) f4v *)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 global_load2(const float2 *p, unsigned i)
+{
+    const f2 v = ((const __attribute__((address_space(1))) f2 *)p)[i];
+    return make_float2(v.x, v.y);
+}
+constexpr unsigned kNoPlane = 0xffffffffu;   // s_src entry of a channel that reads zeros
 
 // per-tile record of crf_tile_active_kernel (TILE_REC ints): [0] = count A of listed labels,
 // [REC_MASK .. REC_MASK+MASK_WORDS) = bit mask, [REC_LAB .. REC_LAB+A) = the labels, ascending
@@ -133,10 +166,11 @@ __device__ __forceinline__ void trace_planes(const f2 (&v)[NC], float sign, floa
 // (compact planes, synthesised unary).  m[c] = messages of channel slot c as a packed pair
 // (pixel 0, pixel 1), so the arithmetic is v_pk_*_f32 like the window walk.  The work follows the tile's channel
 // count: slots are visited in groups of four behind one uniform test per group, and what depends on a slot's role
-// comes from s_tab[c] = (multiplicity, evidence, unary, -): multiplicity 1 for a listed label, n_rest for the
+// comes from s_tab[c] = (multiplicity, evidence, unary, plane offset): multiplicity 1 for a listed label, n_rest for the
 // representative, 0 for an unused slot of the last group; evidence of the constant "unassigned" input at the last
 // channel (find_surfaces.py:356-357, 451-452); unary potential of the slot's label at a pixel that does not belong to
-// it: 10 for label 0, 1 otherwise (:459-472), +inf for an unused slot (probability 0).
+// it: 10 for label 0, 1 otherwise (:459-472), +inf for an unused slot (probability 0); label * pixels as the bits of
+// an unsigned (below 2^32: the host checks), where the slot's plane starts in Qout.
 // TRACE (diagnostic builds): d.potentials and d.trace_q, where not null, receive the softmax argument and the new
 // probabilities of all S labels.
 template <int NC, bool TRACE = false>
@@ -221,7 +255,7 @@ __device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_li
                     }
                 }
             }
-            d.surfaces[p[i]] = best == S - 1 ? 0 : best;
+            global_ptr(d.surfaces)[p[i]] = best == S - 1 ? 0 : best;
         }
         if (TRACE && d.trace_q) trace_planes<NC>(m, 1.0f, d.trace_q, s_list, S, No, p, ok, valid);
         return;
@@ -234,8 +268,9 @@ __device__ __forceinline__ void finish_pair_compact(f2 (&m)[NC], const int *s_li
             const f2 q = m[c] * inv_den;
             if (TRACE) m[c] = q;
             const float ov = lab == 0 ? 0.0f : pv;                       // Q[depth == 0] = prob, :520-525
-            if (ok[0]) d.Qout[(size_t)lab * No + p[0]] = valid[0] ? q.x : ov;
-            if (ok[1]) d.Qout[(size_t)lab * No + p[1]] = valid[1] ? q.y : ov;
+            const unsigned plane = __float_as_uint(s_tab[c].w);
+            if (ok[0]) global_ptr(d.Qout)[plane + p[0]] = valid[0] ? q.x : ov;
+            if (ok[1]) global_ptr(d.Qout)[plane + p[1]] = valid[1] ? q.y : ov;
         }
     }
     if (TRACE && d.trace_q) trace_planes<NC>(m, 1.0f, d.trace_q, s_list, S, No, p, ok, valid);

@@ -59,6 +59,17 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
     const f2 cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
     (void)cinv;
+    // Gaussian kernels: the squared relative depth difference u = ((dq - dp) / (dp + dq))^2 without a division per
+    // neighbour.  With e = dq - dp (exact: depths are 16-bit integers) and a = 1 / (2 dp), (dq - dp) / (dp + dq) =
+    // ea / (1 + ea) and u = (ea)^2 (1 - 2 ea + 3 (ea)^2 - ...).  The series is cut after the third term: its error,
+    // 4 (ea)^3 relative to u, changes a similarity by at most 8e-7 of its weight (largest where the widest kernel has
+    // fallen to a tenth; a neighbour whose similarity is not negligible has |ea| < 0.04), which is the size of the
+    // float32 rounding in the rest of the evaluation.  The constants carry a: u / a^2 = e^2 (1 + e (3 a^2 e - 2 a)).
+    const f2 ha = f2{cd.x == 0.0f ? 0.0f : 0.5f / cd.x, cd.y == 0.0f ? 0.0f : 0.5f / cd.y};
+    const f2 ha2 = ha * ha;
+    const f2 pB = ha * f2{-2.0f, -2.0f}, pC = ha2 * f2{3.0f, 3.0f};
+    const f2 KA1 = ha2 * f2{K.K1, K.K1}, KA2 = ha2 * f2{K.K2, K.K2}, KA3 = ha2 * f2{K.K3, K.K3};
+    (void)pB; (void)pC; (void)KA1; (void)KA2; (void)KA3;
     // region rows jr = 0 .. 2r+1 (LDS row trow + jr); row i of the lane sees row jr at dy = jr - r - i.
     // The operands of the next window position are read from LDS before the arithmetic of the current
     // one starts (the scheduling barriers keep that order), so the read latency hides behind ~150 cycles
@@ -94,13 +105,24 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
         f2 sv;
         if (MODE == 0) {
             // Gaussian kernels (find_surfaces.py:339-355); wtab = (w1', w2', w3', bias)
-            const f2 den = cd + dj;
-            const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            const f2 t = (dj - cd) * inv;
-            const f2 u = t * t;
-            const f2 x1 = FOLD ? __builtin_elementwise_fma(f2{K.K1, K.K1}, u, f2{w0.x, w1.x}) : f2{K.K1, K.K1} * u;
-            const f2 x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);     // colours and angles are stored pre-scaled
-            const f2 x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
+            f2 x1, x2, x3;
+            if (FS_DEPTH_SERIES) {
+                const f2 e = dj - cd;
+                const f2 q = e * e;
+                const f2 g = __builtin_elementwise_fma(e, __builtin_elementwise_fma(e, pC, pB), f2{1.0f, 1.0f});
+                const f2 u = q * g;                                              // u / a^2
+                x1 = FOLD ? __builtin_elementwise_fma(KA1, u, f2{w0.x, w1.x}) : KA1 * u;
+                x2 = __builtin_elementwise_fma(KA2, u, ec);                      // colours and angles are stored pre-scaled
+                x3 = __builtin_elementwise_fma(KA3, u, ea);
+            } else {
+                const f2 den = cd + dj;
+                const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const f2 t = (dj - cd) * inv;
+                const f2 u = t * t;
+                x1 = FOLD ? __builtin_elementwise_fma(f2{K.K1, K.K1}, u, f2{w0.x, w1.x}) : f2{K.K1, K.K1} * u;
+                x2 = __builtin_elementwise_fma(f2{K.K2, K.K2}, u, ec);
+                x3 = __builtin_elementwise_fma(f2{K.K3, K.K3}, u, ea);
+            }
             const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
             const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
             const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
@@ -121,6 +143,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
                  __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
                  __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
         }
+        if (FS_SKIPSIM) sv = f2{a.fa.x + a.fb.x, b.fa.y + b.fb.y};       // timing experiments: the walk without the similarity's arithmetic
         // acc[i][k]: pixel i, channel k.  Two adjacent channels of one pixel make a packed operation (the similarity of
         // the pixel in both halves), in the shared rows and in the pass where each pixel has its own neighbour alike.
 #pragma unroll
@@ -209,7 +232,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     __shared__ unsigned s_ticket;
     extern __shared__ float4 lds4[];          // [2][LH][LW] Q quads | [LH][LW] (d,r,g,b) | [LH][LW] (a0,a1) as float2
     __shared__ int s_list[TILE_REC];
-    __shared__ int s_src[15][NCH * CH];       // plane to read channel c from in each of the 5x3 tiles the region can touch (-1: zero)
+    // where to read channel c in each of the 5x3 tiles the region can touch: offset of the plane in Qin, in elements
+    // (label * pixels, below 2^32: the host checks), or kNoPlane for zeros; read four channels at a time
+    __shared__ __attribute__((aligned(16))) unsigned s_src[15][NCH * CH];
     __shared__ int32_t s_nmask[15 * MASK_WORDS];   // label masks of those tiles
     __shared__ float4 s_tab[NCH * CH];             // (multiplicity, evidence, unary, -) of every channel slot
 
@@ -288,14 +313,14 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     // while a block waits on one.  Everything that needs only the tile's position is therefore requested in
     // one go: the tile's label record, the label masks of the 5x3 tiles the staged region touches, the
     // lane's own depths and patch labels, and the first half of the feature records.
-    const int32_t *rec = d.tile_recs + ((size_t)by * tiles_x + bx) * TILE_REC;
+    const auto *rec = global_ptr(d.tile_recs) + ((size_t)by * tiles_x + bx) * TILE_REC;
     const int32_t rec_word = rec[tid];                       // count, mask and the first 256 - REC_LAB labels
     const int listed_labels = rec[0];                        // (every lane: lane 0 rewrites the LDS copy below)
     int32_t nb_word = 0;
     if (!first && tid < 15 * MASK_WORDS) {
         const int st = tid / MASK_WORDS, sy = by + st / 3 - 2, sx = bx + st % 3 - 1;
         if (sy >= 0 && sy < tiles_y && sx >= 0 && sx < tiles_x)
-            nb_word = d.tile_recs[((size_t)sy * tiles_x + sx) * TILE_REC + REC_MASK + (tid - st * MASK_WORDS)];
+            nb_word = global_ptr(d.tile_recs)[((size_t)sy * tiles_x + sx) * TILE_REC + REC_MASK + (tid - st * MASK_WORDS)];
     }
     bool ok[2], valid[2];
     unsigned p[2];
@@ -306,8 +331,8 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         const int gy = iy0 + trow + i;
         ok[i] = lane_on && gx < Wi && gy < Hi;
         p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
-        valid[i] = ok[i] && d.depth_raw[p[i]] != 0;        // overridden pixels need no message
-        own[i] = ok[i] ? d.patches[p[i]] : 0;
+        valid[i] = ok[i] && global_ptr(d.depth_raw)[p[i]] != 0;        // overridden pixels need no message
+        own[i] = ok[i] ? global_ptr(d.patches)[p[i]] : 0;
         any_work |= valid[i];
     }
     // features of tile + halo (zero outside the frame, like the reference's padded feature maps): flat index
@@ -321,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
             fa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             fb[u] = make_float2(0.f, 0.f);
             if (i < staged && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi) {
-                const size_t q = (size_t)gy * Wi + gxx;
-                fa[u] = d.featA[q];
-                fb[u] = d.featB[q];
+                const unsigned q = (unsigned)gy * (unsigned)Wi + (unsigned)gxx;
+                fa[u] = global_load4(d.featA, q);
+                fb[u] = global_load2(d.featB, q);
             }
         }
     };
@@ -384,14 +409,17 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
 
     if (tid < NCH * CH) {
         const int n_rest = s_list[1], rep_pos = s_list[2];
+        // (multiplicity, evidence, unary, offset of the label's plane in elements as its bit pattern)
         s_tab[tid] = make_float4(tid >= CE ? 0.0f : (tid == rep_pos ? (float)n_rest : 1.0f), tid == CE - 1 ? K.evidence : 0.0f,
-                                 tid >= CE ? INFINITY : (tid == 0 ? 10.0f : 1.0f), 0.0f);
+                                 tid >= CE ? INFINITY : (tid == 0 ? 10.0f : 1.0f),
+                                 __uint_as_float(tid < CE ? (unsigned)s_list[REC_LAB + tid] * (unsigned)Ni : 0u));
     }
     // ---- where to read each of my channels in the 5x3 tiles the staged region touches ----
     if (block_work && !first && tid < 15) {
         const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
+        const int CE8 = (CE + 7) & ~7;                              // the chunks are staged whole
         if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
+            for (int c = 0; c < CE8; ++c) s_src[tid][c] = kNoPlane;
         } else {
             const int32_t *m = s_nmask + tid * MASK_WORDS;
             int rp = 1;                                             // representative of the source tile
@@ -399,8 +427,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
             for (int c = 0; c < CE; ++c) {
                 const int l = s_list[REC_LAB + c];
                 const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = listed ? l : rp;
+                s_src[tid][c] = (unsigned)(listed ? l : rp) * (unsigned)Ni;
             }
+            for (int c = CE; c < CE8; ++c) s_src[tid][c] = kNoPlane;
         }
     }
     if (block_work) {
@@ -438,10 +467,10 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                     const int ly = i / LW, lx = i - ly * LW;
                     const int gy = iy0 - r + ly, gxx = ix0 - r + lx;
                     const bool in = i < staged && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
-                    const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+                    const unsigned q = in ? (unsigned)gy * (unsigned)Wi + (unsigned)gxx : 0u;
                     const bool upper = CE - ch * CH > 4;     // channels 4..7 of the chunk are in use (uniform)
                     if (first) {
-                        const int lab = in ? d.patches[q] : -1;
+                        const int lab = in ? global_ptr(d.patches)[q] : -1;
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
                             v[u][k] = 0.0f;
@@ -451,13 +480,19 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                             }
                         }
                     } else {
+                        // the planes of the pixel's four or eight channels come with one or two LDS reads, and nothing
+                        // waits between the loads of a pixel (global loads do not count as LDS operations)
                         const int st = in ? ((gy >> (TH == 16 ? 4 : 3)) - by + 2) * 3 + ((gxx >> 5) - bx + 1) : 0;
+                        const uint4 *src4 = reinterpret_cast<const uint4 *>(&s_src[st][ch * CH]);
+                        const uint4 none4 = make_uint4(kNoPlane, kNoPlane, kNoPlane, kNoPlane);
+                        const uint4 o0 = in ? src4[0] : none4, o1 = (in && upper) ? src4[1] : none4;
+                        const unsigned off[CH] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                        const gfloat *Qg = global_ptr(d.Qin);
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
                             v[u][k] = 0.0f;
                             if (k < 4 || upper) {
-                                const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
-                                if (l >= 0) v[u][k] = d.Qin[(size_t)l * Ni + q];
+                                if (off[k] != kNoPlane) v[u][k] = Qg[off[k] + q];
                             }
                         }
                     }

@@ -31,6 +31,7 @@ struct RollOperands { float4 fa; float2 fb; float4 q0, q1; };
 template <int NQ, int MODE, bool FOLD>
 struct PairSim {
     f2 cd, cr, cg, cb, ca0, ca1, cinv;
+    f2 pB, pC, KA1, KA2, KA3;          // constants of the series for the squared relative depth difference (fused_accumulate)
     float K1, K2, K3;
 
     __device__ __forceinline__ void step(f2 (&acc)[8], const RollOperands &a, const float4 &w0, const float4 &w1) const
@@ -43,13 +44,24 @@ struct PairSim {
         const f2 ea = __builtin_elementwise_fma(g1, g1, FOLD ? __builtin_elementwise_fma(g0, g0, f2{w0.z, w1.z}) : g0 * g0);
         f2 sv;
         if (MODE == 0) {
-            const f2 den = cd + dj;
-            const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            const f2 t = (dj - cd) * inv;
-            const f2 u = t * t;
-            const f2 x1 = FOLD ? __builtin_elementwise_fma(f2{K1, K1}, u, f2{w0.x, w1.x}) : f2{K1, K1} * u;
-            const f2 x2 = __builtin_elementwise_fma(f2{K2, K2}, u, ec);
-            const f2 x3 = __builtin_elementwise_fma(f2{K3, K3}, u, ea);
+            f2 x1, x2, x3;
+            if (FS_DEPTH_SERIES) {
+                const f2 e = dj - cd;
+                const f2 q = e * e;
+                const f2 g = __builtin_elementwise_fma(e, __builtin_elementwise_fma(e, pC, pB), f2{1.0f, 1.0f});
+                const f2 u = q * g;                                              // u / a^2, a = 1 / (2 d_p)
+                x1 = FOLD ? __builtin_elementwise_fma(KA1, u, f2{w0.x, w1.x}) : KA1 * u;
+                x2 = __builtin_elementwise_fma(KA2, u, ec);
+                x3 = __builtin_elementwise_fma(KA3, u, ea);
+            } else {
+                const f2 den = cd + dj;
+                const f2 inv = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                const f2 t = (dj - cd) * inv;
+                const f2 u = t * t;
+                x1 = FOLD ? __builtin_elementwise_fma(f2{K1, K1}, u, f2{w0.x, w1.x}) : f2{K1, K1} * u;
+                x2 = __builtin_elementwise_fma(f2{K2, K2}, u, ec);
+                x3 = __builtin_elementwise_fma(f2{K3, K3}, u, ea);
+            }
             const f2 s1 = f2{__builtin_amdgcn_exp2f(-x1.x), __builtin_amdgcn_exp2f(-x1.y)};
             const f2 s2 = f2{__builtin_amdgcn_exp2f(-x2.x), __builtin_amdgcn_exp2f(-x2.y)};
             const f2 s3 = f2{__builtin_amdgcn_exp2f(-x3.x), __builtin_amdgcn_exp2f(-x3.y)};
@@ -158,7 +170,9 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     __shared__ unsigned s_ticket;
     extern __shared__ float4 lds4[];          // ring: [2][RING][LW] Q quads | [RING][LW] (d,r,g,b) | [RING][LW] (a0,a1) as float2
     __shared__ int s_list[TILE_REC];
-    __shared__ int s_src[9][NCH * CH];        // plane to read channel c from in each of the 3x3 tiles the region touches (-1: zero)
+    // where to read channel c in each of the 3x3 tiles the region touches: offset of the plane in Qin in elements
+    // (label * pixels), or kNoPlane for zeros; read four channels at a time
+    __shared__ __attribute__((aligned(16))) unsigned s_src[9][NCH * CH];
     __shared__ int32_t s_nmask[9 * MASK_WORDS];    // label masks of those tiles
     __shared__ float4 s_tab[NCH * CH];             // (multiplicity, evidence, unary, -) of every channel slot
 
@@ -218,14 +232,14 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int gx = ix0 + col;
 
     // ---- set-up: everything that needs only the tile's position is requested in one go ----
-    const int32_t *rec = d.tile_recs + ((size_t)by * tiles_x + bx) * TILE_REC;
+    const auto *rec = global_ptr(d.tile_recs) + ((size_t)by * tiles_x + bx) * TILE_REC;
     const int32_t rec_word = rec[tid];                       // count, mask and the first 256 - REC_LAB labels
     const int listed_labels = rec[0];
     int32_t nb_word = 0;
     if (!first && tid < 9 * MASK_WORDS) {
         const int st = tid / MASK_WORDS, sy = by + st / 3 - 1, sx = bx + st % 3 - 1;
         if (sy >= 0 && sy < tiles_y && sx >= 0 && sx < tiles_x)
-            nb_word = d.tile_recs[((size_t)sy * tiles_x + sx) * TILE_REC + REC_MASK + (tid - st * MASK_WORDS)];
+            nb_word = global_ptr(d.tile_recs)[((size_t)sy * tiles_x + sx) * TILE_REC + REC_MASK + (tid - st * MASK_WORDS)];
     }
     bool ok[2], valid[2];
     unsigned p[2];
@@ -236,20 +250,20 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         const int gy = iy0 + trow + i;
         ok[i] = gx < Wi && gy < Hi;
         p[i] = ok[i] ? (unsigned)gy * (unsigned)Wi + (unsigned)gx : 0u;
-        valid[i] = ok[i] && d.depth_raw[p[i]] != 0;        // overridden pixels need no message
-        own[i] = ok[i] ? d.patches[p[i]] : 0;
+        valid[i] = ok[i] && global_ptr(d.depth_raw)[p[i]] != 0;        // overridden pixels need no message
+        own[i] = ok[i] ? global_ptr(d.patches)[p[i]] : 0;
         any_work |= valid[i];
     }
     // the pair's own features (its rows enter the ring only at a later step when r + trow + 1 > 15)
     f2 cd = f2{0.f, 0.f}, cr = cd, cg = cd, cb = cd, ca0 = cd, ca1 = cd;
     if (ok[0]) {
-        const float4 a = d.featA[p[0]];
-        const float2 b = d.featB[p[0]];
+        const float4 a = global_load4(d.featA, p[0]);
+        const float2 b = global_load2(d.featB, p[0]);
         cd.x = a.x; cr.x = a.y; cg.x = a.z; cb.x = a.w; ca0.x = b.x; ca1.x = b.y;
     }
     if (ok[1]) {
-        const float4 a = d.featA[p[1]];
-        const float2 b = d.featB[p[1]];
+        const float4 a = global_load4(d.featA, p[1]);
+        const float2 b = global_load2(d.featB, p[1]);
         cd.y = a.x; cr.y = a.y; cg.y = a.z; cb.y = a.w; ca0.y = b.x; ca1.y = b.y;
     }
     s_list[tid] = rec_word;
@@ -284,14 +298,17 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int CE = s_list[0];
     if (tid < NCH * CH) {
         const int n_rest = s_list[1], rep_pos = s_list[2];
+        // (multiplicity, evidence, unary, offset of the label's plane in elements as its bit pattern)
         s_tab[tid] = make_float4(tid >= CE ? 0.0f : (tid == rep_pos ? (float)n_rest : 1.0f), tid == CE - 1 ? K.evidence : 0.0f,
-                                 tid >= CE ? INFINITY : (tid == 0 ? 10.0f : 1.0f), 0.0f);
+                                 tid >= CE ? INFINITY : (tid == 0 ? 10.0f : 1.0f),
+                                 __uint_as_float(tid < CE ? (unsigned)s_list[REC_LAB + tid] * (unsigned)Ni : 0u));
     }
     // where to read each of my channels in the 3x3 tiles the region touches (r <= 15 < tile sides)
     if (block_work && !first && tid < 9) {
         const int sy = by + tid / 3 - 1, sx = bx + tid % 3 - 1;
+        const int CE8 = (CE + 7) & ~7;                              // the chunks are staged whole
         if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE; ++c) s_src[tid][c] = -1;
+            for (int c = 0; c < CE8; ++c) s_src[tid][c] = kNoPlane;
         } else {
             const int32_t *m = s_nmask + tid * MASK_WORDS;
             int rp = 1;                                             // representative of the source tile
@@ -299,8 +316,9 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
             for (int c = 0; c < CE; ++c) {
                 const int l = s_list[REC_LAB + c];
                 const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = listed ? l : rp;
+                s_src[tid][c] = (unsigned)(listed ? l : rp) * (unsigned)Ni;
             }
+            for (int c = CE; c < CE8; ++c) s_src[tid][c] = kNoPlane;
         }
     }
 
@@ -320,15 +338,15 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         PixelRecord t;
         const int gy = iy0 - r + row, gxx = ix0 - r + lx;
         const bool in = want && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
-        const size_t q = in ? (size_t)gy * Wi + gxx : 0;
+        const unsigned q = in ? (unsigned)gy * (unsigned)Wi + (unsigned)gxx : 0u;
         t.fa = make_float4(0.f, 0.f, 0.f, 0.f);
         t.fb = make_float2(0.f, 0.f);
         if (in) {
-            t.fa = d.featA[q];
-            t.fb = d.featB[q];
+            t.fa = global_load4(d.featA, q);
+            t.fb = global_load2(d.featB, q);
         }
         if (first) {
-            const int lab = in ? d.patches[q] : -1;
+            const int lab = in ? global_ptr(d.patches)[q] : -1;
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 t.v[k] = 0.0f;
@@ -338,13 +356,18 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
                 }
             }
         } else {
+            // one or two LDS reads for the planes of the pixel's channels, no wait between the loads of a pixel
             const int st = in ? ((gy >> 4) - by + 1) * 3 + ((gxx >> 5) - bx + 1) : 0;
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(&s_src[st][ch * CH]);
+            const uint4 none4 = make_uint4(kNoPlane, kNoPlane, kNoPlane, kNoPlane);
+            const uint4 o0 = in ? src4[0] : none4, o1 = (in && upper) ? src4[1] : none4;
+            const unsigned off[CH] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            const gfloat *Qg = global_ptr(d.Qin);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 t.v[k] = 0.0f;
                 if (k < 4 || upper) {
-                    const int l = (in && ch * CH + k < CE) ? s_src[st][ch * CH + k] : -1;
-                    if (l >= 0) t.v[k] = d.Qin[(size_t)l * Ni + q];
+                    if (off[k] != kNoPlane) t.v[k] = Qg[off[k] + q];
                 }
             }
         }
@@ -363,6 +386,14 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     sim1.cd = sim2.cd = cd; sim1.cr = sim2.cr = cr; sim1.cg = sim2.cg = cg; sim1.cb = sim2.cb = cb;
     sim1.ca0 = sim2.ca0 = ca0; sim1.ca1 = sim2.ca1 = ca1;
     sim1.cinv = sim2.cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
+    {
+        const f2 ha = f2{cd.x == 0.0f ? 0.0f : 0.5f / cd.x, cd.y == 0.0f ? 0.0f : 0.5f / cd.y}, ha2 = ha * ha;
+        sim1.pB = sim2.pB = ha * f2{-2.0f, -2.0f};
+        sim1.pC = sim2.pC = ha2 * f2{3.0f, 3.0f};
+        sim1.KA1 = sim2.KA1 = ha2 * f2{K.K1, K.K1};
+        sim1.KA2 = sim2.KA2 = ha2 * f2{K.K2, K.K2};
+        sim1.KA3 = sim2.KA3 = ha2 * f2{K.K3, K.K3};
+    }
     const float4 uon = make_float4(K.uw[0], K.uw[1], K.uw[2], 0.0f);
     const int kw = 2 * r + 1;
 

@@ -80,5 +80,8 @@ def test_mirror_lr_mode(oracle):
     assert np.array_equal(step["surfaces"], ref["surfaces"])
     # and back to the Gaussian similarity on the same context
     gauss = fs.find_surface_model("Gauss")((depth, rgb, None))
-    print("label disagreement:", float((gauss["surfaces"] != g["surfaces"]).mean()))
-    assert (gauss["surfaces"] != g["surfaces"]).mean() <= 0.001
+    dis = gauss["surfaces"] != g["surfaces"]
+    print("label disagreement:", float(dis.mean()))
+    top2 = np.sort(g["q_final"][dis], axis=-1)[:, -2:]
+    assert ((top2[:, 1] - top2[:, 0]) <= 1e-5 * top2[:, 1]).all(), "label difference that is not a numerical tie of the oracle"
+    assert dis.mean() <= 0.0015         # a 96 x 128 frame: 18 pixels, all of them ties (measured: 16)
