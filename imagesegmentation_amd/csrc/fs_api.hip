@@ -44,6 +44,7 @@ struct fs_ctx {
     DevBuf cc_parent, cc_count, cc_newid, cc_blocksum;
     // CRF buffers (one frame in flight)
     DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
+    DevBuf msg;                        // message planes of a wide update (one frame at a time)
     HostBuf descs_host;                // page-locked staging of the frame descriptors; descs_copied: its last upload
     hipEvent_t descs_copied = nullptr;
     DevBuf crf_queue;                  // tile queues of the fused CRF update
@@ -512,7 +513,8 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     FS_HIP(ctx->descs_host.ensure(ndesc * sizeof(CrfFrameDesc)));
     CrfFrameDesc *dh = ctx->descs_host.as<CrfFrameDesc>();
     std::fill(dh, dh + ndesc, CrfFrameDesc{});
-    struct Launch { size_t first; int count, cls; };
+    struct Launch { size_t first; int count, cls, wide_channels; };
+    size_t msg_floats = 0;                       // message planes of the largest wide frame
     std::vector<std::vector<Launch>> launches((size_t)ngroups * iterations);
     for (int gi = 0; gi < ngroups; ++gi) {
         const int g0 = gstart[gi], gn = gstart[gi + 1] - g0;
@@ -523,10 +525,14 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             order[k] = k;
             int ce = fused ? max_active[g0 + k] + 3 : S[g0 + k];   // without per-tile lists every label is carried
             if (ce > S[g0 + k]) ce = S[g0 + k];
-            if (ce > kMaxTileChannels)
+            if (ce > kMaxTileChannels && !fused)
                 return ctx->fail("a tile of frame " + std::to_string(g0 + k) + " needs " + std::to_string(ce) + " label channels; at most " +
-                                 std::to_string(kMaxTileChannels) + " are supported");
+                                 std::to_string(kMaxTileChannels) + " are supported by the plane-based update");
             cls[k] = crf_channel_class(ce);
+            if (cls[k] == kCrfWideClass) {
+                if (trace) return ctx->fail("the diagnostic updates carry at most " + std::to_string(kMaxTileChannels) + " channels per tile");
+                msg_floats = std::max(msg_floats, (size_t)S[g0 + k] * N);
+            }
             qoff[k] = q;
             q += (size_t)S[g0 + k] * N;
         }
@@ -552,12 +558,19 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                 d.surfaces = last ? d_surfaces + (size_t)fi * N : nullptr;
                 d.tile_recs = fused ? ctx->tile_recs.as<int32_t>() + (size_t)fi * rec_stride : nullptr;
                 d.S = S[fi];
-                if (k == 0 || cls[order[k]] != cls[order[k - 1]])
-                    launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f]});
+                // frames of one class share a launch; a wide frame (more channels around a tile than the kernels keep in
+                // registers) goes alone, because all of them use the context's one set of message planes in turn
+                const bool wide = cls[f] == kCrfWideClass;
+                if (k == 0 || cls[order[k]] != cls[order[k - 1]] || wide)
+                    launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f], wide ? std::min(S[fi], max_active[fi] + 3) : 0});
                 else
                     launches[(size_t)gi * iterations + it].back().count++;
             }
         }
+    }
+    if (msg_floats) {
+        FS_HIP(ctx->msg.ensure(msg_floats * sizeof(float)));
+        for (size_t i = 0; i < ndesc; ++i) dh[i].msg = ctx->msg.as<float>();       // (only the wide launches read it)
     }
     FS_HIP(ctx->descs.ensure(ndesc * sizeof(CrfFrameDesc)));
     FS_HIP(hipMemcpyAsync(ctx->descs.p, dh, ndesc * sizeof(CrfFrameDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -591,7 +604,8 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                     queue_slot = 0;
                 }
                 unsigned *queue = ctx->crf_queue.as<unsigned>() + (fused ? queue_slot++ : 0) * (kCrfQueueBytes / sizeof(unsigned));
-                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, trace)
+                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, trace,
+                                                             l.wide_channels)
                                      : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
             }
@@ -719,7 +733,7 @@ void fs_destroy(fs_ctx *ctx)
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin,
                       &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB};
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB, &ctx->msg};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

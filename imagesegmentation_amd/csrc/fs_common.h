@@ -90,7 +90,10 @@ struct CrfParams {
 };
 
 constexpr int kMaxLabels = 512;       // label channels S = num_surfaces + 1 of a frame (multiple of 32)
-constexpr int kMaxTileChannels = 128; // channels one tile can carry: listed labels + 3; also the limit of fs_crf_step
+constexpr int kMaxTileChannels = 128; // channels the update kernels carry per tile in registers (listed labels + 3); tiles with more
+                                      // take one pass per 128 channels (kCrfWideClass); also the limit of fs_crf_step
+constexpr int kCrfWideClass = 1 << 10;   // crf_channel_class of such frames; launch_crf_iter_fused then wants wide_channels =
+                                         // the most channels of a tile (descs[].msg must point at S label planes)
 constexpr int kMaxRadius = 15;    // largest CRF window radius (kernel_size)
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----
@@ -199,6 +202,7 @@ struct CrfFrameDesc {            // one frame of a batched launch (device-reside
     float *Qout;                 // label planes [S][oh*ow] or null
     float *potentials;           // label planes [S][oh*ow] or null
     float *trace_q;              // fused update, diagnostic kernels only: all S planes of the new probabilities, or null
+    float *msg;                  // wide updates only: label planes [S][Hi*Wi] for the raw messages between the passes, or null
     const float *unary;          // explicit unary planes [S][oh*ow] or null (then synthesised from patches)
     const int32_t *patches;      // [Hi*Wi] or null
     const uint16_t *depth_raw;   // [Hi*Wi] or null: invalid-depth override (and depth feature of the fused update)
@@ -278,6 +282,6 @@ constexpr int kCrfQueueSlots = 64;
 // with uniform window constants only)
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st,
-                                 bool trace = false);
+                                 bool trace = false, int wide_channels = 0);
 
 }  // namespace fs

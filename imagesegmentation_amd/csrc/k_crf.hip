@@ -599,6 +599,74 @@ __global__ __launch_bounds__(64 * ITH / PY) void crf_iter_kernel(const CrfFrameD
     }
 }
 
+// Second half of a wide update (tiles with more channels than the update kernels keep in registers): the passes of
+// crf_iter_roll_kernel<..., WIDE> have left the raw messages of every channel slot of every tile in d.msg; this kernel
+// walks a tile's channel list per pixel and does what finish_pair_compact does on registers, in the same order: total
+// over all labels (compensated), Potts compatibility, softmax, Q[depth == 0] override, compact planes or the argmax.
+// One block per 32 x 16 tile, two pixels per lane one after the other.
+__global__ __launch_bounds__(256) void crf_wide_finish_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, float weight,
+                                                             float evidence, int last)
+{
+    __shared__ int s_list[TILE_REC + 8];
+    const CrfFrameDesc d = descs[blockIdx.z];
+    const int S = d.S, Wi = g.Wi, Hi = g.Hi;
+    const unsigned Ni = (unsigned)Hi * (unsigned)Wi;
+    const int tiles_x = (Wi + FTW - 1) / FTW;
+    build_channel_list<256>(s_list, d.tile_recs, blockIdx.y * tiles_x + blockIdx.x, S);
+    const int CE = s_list[0], n_rest = s_list[1], rep_pos = s_list[2];
+    const float pv = (float)(1.0 / (double)(S - 1));
+    for (int i = threadIdx.x; i < FTW * 16; i += 256) {
+        const int gx = blockIdx.x * FTW + (i & (FTW - 1)), gy = blockIdx.y * 16 + i / FTW;
+        if (gx >= Wi || gy >= Hi) continue;
+        const unsigned p = (unsigned)gy * (unsigned)Wi + (unsigned)gx;
+        const bool valid = global_ptr(d.depth_raw)[p] != 0;
+        const int own = global_ptr(d.patches)[p];
+        const int key = own != 0 ? own : -1;
+        const gfloat *M = global_ptr(d.msg);
+        auto message = [&](int c) { return M[(unsigned)s_list[REC_LAB + c] * Ni + p] + (c == CE - 1 ? evidence : 0.0f); };
+        auto mult = [&](int c) { return c == rep_pos ? (float)n_rest : 1.0f; };
+        float tot = 0.0f, tot_lo = 0.0f, mx = -INFINITY, den = 0.0f;
+        if (valid) {
+            for (int c = 0; c < CE; ++c) {
+                const float term = message(c) * mult(c);
+                const float t = tot + term, bp = t - tot;
+                tot_lo += (tot - (t - bp)) + (term - bp);
+                tot = t;
+            }
+        }
+        auto argument = [&](int c) {
+            const int lab = s_list[REC_LAB + c];
+            const float comp = (tot - message(c)) + tot_lo;                           // find_surfaces.py:297-298, 360
+            const float un = lab == key ? 0.0f : (c == 0 ? 10.0f : 1.0f);             // :459-472
+            return -(un + weight * comp);                                             // :361
+        };
+        if (valid) {
+            for (int c = 0; c < CE; ++c) mx = fmaxf(mx, argument(c));
+            for (int c = 0; c < CE; ++c) den = fmaf(__builtin_amdgcn_exp2f((argument(c) - mx) * 1.44269504088896341f), mult(c), den);
+        }
+        if (last) {
+            int best = 0;
+            float bestv = -1.0f;
+            if (valid) {
+                for (int c = 0; c < CE; ++c) {
+                    const int lab = s_list[REC_LAB + c];
+                    const float v = __builtin_amdgcn_exp2f((argument(c) - mx) * 1.44269504088896341f) / den;
+                    if (v > bestv || (v == bestv && lab < best)) { bestv = v; best = lab; }    // first maximum, :531
+                }
+            }
+            global_ptr(d.surfaces)[p] = best == S - 1 ? 0 : best;                     // :532
+        } else {
+            const float inv_den = 1.0f / den;
+            for (int c = 0; c < CE; ++c) {
+                const int lab = s_list[REC_LAB + c];
+                float q = lab == 0 ? 0.0f : pv;                                       // Q[depth == 0] = prob, :520-525
+                if (valid) q = __builtin_amdgcn_exp2f((argument(c) - mx) * 1.44269504088896341f) * inv_den;
+                global_ptr(d.Qout)[(unsigned)lab * Ni + p] = q;
+            }
+        }
+    }
+}
+
 // depth u16 / rgb u8 / angles -> the float records the fused update stages: (d, r, g, b) and (a0, a1).
 // Colours and angles carry the square root of their coefficient in the Gaussian exponents (cscale, ascale),
 // so that squared differences of the stored values are the exponent terms themselves; 1 for the linear similarity.
@@ -683,7 +751,8 @@ int crf_channel_class(int channels)
     if (nch <= 2) return 2;       // one launch for the bulk of the frames: the 16-channel variant is as fast on 8
     if (nch <= 4) return nch;
     if (nch <= 8) return 8;
-    return 16;
+    if (nch <= 16) return 16;
+    return kCrfWideClass;         // more channels around a tile than a lane's registers hold: passes through memory
 }
 
 void launch_crf_sim(const uint16_t *depth, const uint8_t *rgb, const float *angles, const CrfParams &p,
@@ -766,7 +835,8 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
 }
 
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
-                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st, bool trace)
+                                 const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st, bool trace,
+                                 int wide_channels)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
@@ -783,7 +853,23 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     K.uw[0] = (float)-std::log2((double)P.w1); K.uw[1] = (float)-std::log2((double)P.w2); K.uw[2] = (float)-std::log2((double)P.w3);
     K.uw[3] = 0.0f;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
-    const FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st, trace};
+    FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st, trace};
+    if (channel_class == kCrfWideClass) {
+        // one pass per window of kMaxTileChannels channel slots, messages to descs[].msg, then the finishing kernel
+        if (trace || wide_channels < 1) return hipErrorInvalidValue;
+        const int variant = P.mode == 1 ? 2 : (uniform ? 0 : 1);
+        for (int c0 = 0; c0 < wide_channels; c0 += kMaxTileChannels) {
+            if (c0 > 0) {                       // (the caller hands over a zeroed tile queue: good for the first pass)
+                if (hipError_t e = hipMemsetAsync(tile_queue, 0, kCrfQueueBytes, st); e != hipSuccess) return e;
+            }
+            L.c0 = c0;
+            if (hipError_t e = launch_roll_wide(variant, L); e != hipSuccess) return e;
+        }
+        int tx, ty;
+        crf_fused_tile_grid(g.Hi, g.Wi, g.r, &tx, &ty);
+        hipLaunchKernelGGL(crf_wide_finish_kernel, dim3(tx, ty, nframes), dim3(256), 0, st, descs, g, P.weight, P.evidence, last);
+        return hipGetLastError();
+    }
     if (trace) return uniform ? launch_fused_trace(channel_class, L) : hipErrorInvalidValue;
     if (P.mode == 1) return launch_roll_table(2, channel_class, L);
     if (!uniform) return launch_roll_table(1, channel_class, L);

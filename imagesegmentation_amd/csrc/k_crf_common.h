@@ -43,6 +43,7 @@ struct FusedLaunch {
     unsigned *queue;
     hipStream_t st;
     bool trace = false;      // the diagnostic kernels, which also write CrfFrameDesc::potentials and trace_q
+    int c0 = 0;              // wide passes (launch_roll_wide): first channel slot of the pass
 };
 // Instance files (k_crf_fused_*.hip): each compiles the kernel variants it names and returns
 // hipErrorInvalidValue for a combination it does not carry.
@@ -51,6 +52,9 @@ struct FusedLaunch {
 hipError_t launch_fused_r7_uniform(int channel_class, const FusedLaunch &L);      // static tile + halo in LDS, r = 7
 hipError_t launch_roll_uniform(int channel_class, const FusedLaunch &L);          // rolling window, variant 0, any radius
 hipError_t launch_roll_table(int variant, int channel_class, const FusedLaunch &L);   // rolling window, variants 1 and 2
+// one pass of a wide update (more channels per tile than kMaxTileChannels): the messages of channel slots
+// [L.c0, L.c0 + kMaxTileChannels) of every tile to descs[].msg; variant as above, any radius (k_crf_roll_t.hip)
+hipError_t launch_roll_wide(int variant, const FusedLaunch &L);
 // the same kernels built with their diagnostic outputs (variant 0 at any radius; k_crf_trace.hip)
 hipError_t launch_fused_trace(int channel_class, const FusedLaunch &L);
 

@@ -160,16 +160,21 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
 template <int R>
 constexpr int roll_blocks_per_cu() { return (R > 0 && (FTW + 2 * R) * RING * 56 + 6 * 1024 <= 160 * 1024 / 3) ? 3 : 2; }
 
-template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
+// WIDE: one pass of an update whose tiles carry more channels than a lane's registers hold (NCH * 8).  The pass works on
+// the channel slots [c0, c0 + NCH * 8) of every tile's list and, instead of finishing the update, leaves the raw messages
+// of those slots in descs[].msg (label planes like Q); the host runs one pass per window of slots and then
+// crf_wide_finish_kernel, which reads the messages back and does what finish_pair_compact does on registers.
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false>
 __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
-                                                            int nframes, unsigned *__restrict__ queue)
+                                                            int nframes, unsigned *__restrict__ queue, int c0_arg)
 {
     constexpr int CH = 8, TH = RING;
     constexpr bool FOLD = UNIFORM && MODE == 0;
     __shared__ unsigned s_ticket;
     extern __shared__ float4 lds4[];          // ring: [2][RING][LW] Q quads | [RING][LW] (d,r,g,b) | [RING][LW] (a0,a1) as float2
-    __shared__ int s_list[TILE_REC];
+    __shared__ int s_list[TILE_REC + 8];      // (a list of every label, the representative's slot and the padding included)
+    const int c0 = WIDE ? c0_arg : 0;         // first channel slot of this pass
     // where to read channel c in each of the 3x3 tiles the region touches: offset of the plane in Qin in elements
     // (label * pixels), or kNoPlane for zeros; read four channels at a time
     __shared__ __attribute__((aligned(16))) unsigned s_src[9][NCH * CH];
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
-    const int r = R ? R : g.r, S = frame_channels(d, NCH * CH);
+    const int r = R ? R : g.r, S = WIDE ? d.S : frame_channels(d, NCH * CH);
     if (S == 0) {                                            // enqueued ahead of the label count, and the frame does not fit
         __syncthreads();                                     // (every lane has read the ticket)
         if (threadIdx.x == 0) s_ticket = claim_early ? next_ticket : next_tile();
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     }
     __syncthreads();
     const int CE = s_list[0];
-    if (tid < NCH * CH) {
+    if (!WIDE && tid < NCH * CH) {
         const int n_rest = s_list[1], rep_pos = s_list[2];
         // (multiplicity, evidence, unary, offset of the label's plane in elements as its bit pattern)
         s_tab[tid] = make_float4(tid >= CE ? 0.0f : (tid == rep_pos ? (float)n_rest : 1.0f), tid == CE - 1 ? K.evidence : 0.0f,
@@ -306,19 +311,20 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     // where to read each of my channels in the 3x3 tiles the region touches (r <= 15 < tile sides)
     if (block_work && !first && tid < 9) {
         const int sy = by + tid / 3 - 1, sx = bx + tid % 3 - 1;
-        const int CE8 = (CE + 7) & ~7;                              // the chunks are staged whole
+        const int slots = min(CE - c0, NCH * CH);                   // channel slots of this pass (all of them unless WIDE)
+        const int slots8 = (slots + 7) & ~7;                        // the chunks are staged whole
         if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE8; ++c) s_src[tid][c] = kNoPlane;
+            for (int c = 0; c < slots8; ++c) s_src[tid][c] = kNoPlane;
         } else {
             const int32_t *m = s_nmask + tid * MASK_WORDS;
             int rp = 1;                                             // representative of the source tile
             while (rp < S - 1 && ((unsigned)m[rp >> 5] >> (rp & 31) & 1u)) ++rp;
-            for (int c = 0; c < CE; ++c) {
-                const int l = s_list[REC_LAB + c];
+            for (int c = 0; c < slots; ++c) {
+                const int l = s_list[REC_LAB + c0 + c];
                 const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
                 s_src[tid][c] = (unsigned)(listed ? l : rp) * (unsigned)Ni;
             }
-            for (int c = CE; c < CE8; ++c) s_src[tid][c] = kNoPlane;
+            for (int c = max(slots, 0); c < slots8; ++c) s_src[tid][c] = kNoPlane;
         }
     }
 
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
             for (int k = 0; k < CH; ++k) {
                 t.v[k] = 0.0f;
                 if (k < 4 || upper) {
-                    const int l = ch * CH + k < CE ? s_list[REC_LAB + ch * CH + k] : -1;
+                    const int l = c0 + ch * CH + k < CE ? s_list[REC_LAB + c0 + ch * CH + k] : -1;
                     if (lab >= 0 && l > 0) t.v[k] = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
                 }
             }
@@ -399,8 +405,8 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        if (block_work && ch * CH < CE) {
-            const bool upper = CE - ch * CH > 4;             // channels 4..7 of the chunk are in use (uniform)
+        if (block_work && c0 + ch * CH < CE) {
+            const bool upper = CE - (c0 + ch * CH) > 4;      // channels 4..7 of the chunk are in use (uniform)
             if (ch > 0) __syncthreads();                     // the previous chunk's last row is read no more
             // ---- region rows 0 .. 15 fill the ring: flat index over 16 x LW pixels, two per thread and pass ----
             const int staged = RING * LW;
@@ -438,7 +444,18 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     }
 
     if (!claim_early && threadIdx.x == 0) next_ticket = next_tile();
-    if (FS_SKIPFIN) {                              // timing experiments: keep the messages alive without the epilogue
+    if (WIDE) {
+        // this pass's raw messages to the planes of their labels (the representative's slot to the representative's)
+        float *msg = d.msg;
+#pragma unroll
+        for (int c = 0; c < NCH * CH; ++c) {
+            if (c0 + c < CE) {
+                const unsigned plane = (unsigned)s_list[REC_LAB + c0 + c] * (unsigned)Ni;
+                if (ok[0]) global_ptr(msg)[plane + p[0]] = acc[c / CH][c % CH].x;
+                if (ok[1]) global_ptr(msg)[plane + p[1]] = acc[c / CH][c % CH].y;
+            }
+        }
+    } else if (FS_SKIPFIN) {                       // timing experiments: keep the messages alive without the epilogue
         f2 t = f2{0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < NCH * CH; ++c) t += acc[c / CH][c % CH];
@@ -454,11 +471,11 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
   }
 }
 
-template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false>
 hipError_t launch_roll_t(const FusedLaunch &L)
 {
     static LdsAllowance allowed;
-    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM, TRACE>;
+    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM, TRACE, WIDE>;
     const CrfGeom &g = L.g;
     if (R && g.r != R) return hipErrorInvalidValue;
     const size_t lds = (size_t)(FTW + 2 * g.r) * RING * (3 * sizeof(float4) + sizeof(float2));
@@ -468,7 +485,7 @@ hipError_t launch_roll_t(const FusedLaunch &L)
     const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, as many as the chip holds at once
     const unsigned resident = 256u * roll_blocks_per_cu<R>();
     dim3 grid(nblk < resident ? nblk : resident);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.c0);
     return hipGetLastError();
 }
 
