@@ -13,7 +13,8 @@ frames.  Workloads (--workload):
   synthetic640   seeded synthetic scenes of the same shape (also the fallback when data/osd is missing)
   synthetic1280  seeded synthetic scenes 1280x960 with sensor-like noise (hundreds of label channels)
   mosaic1280     seeded 1280x960 scenes with a prescribed channel count S (--labels S, 16 / 32 / 64) for the larger
-                 CRF windows (--kernel-size 7 / 10 / 15)
+                 CRF windows (--kernel-size 7 / 10 / 15); the facets lie in separate cells, a tile sees few of them
+  dense1280      seeded 1280x960 scenes with about 420 surfaces close together (20 to 50 labels around a tile)
   stream640      a stream of seeded synthetic 640x480 frames, frame id % n_gpu == rank, that enters and leaves
                  through page-locked host memory every step: PCIe copies are inside the timed region, so several
                  ranks on one node compete for the host, which an HBM-resident loop cannot show.
@@ -40,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector (packed FMA): 256 CUs x 128 lanes x 2 flop x 2.4 GHz
-SIM_FLOPS = 45               # similarity of one pixel pair: 3 exponentials, 1 reciprocal, ~41 multiply-adds
+SIM_FLOPS = 33               # similarity of one pixel pair: 3 exponentials and 30 flops in adds, multiplies and fused multiply-adds
 
 
 def load_frames(workload, count, rank, world, labels):
@@ -54,7 +55,11 @@ def load_frames(workload, count, rank, world, labels):
             c = np.stack([read_png(os.path.join(base, "RGB", f"{i}.png")) for i in idx])
             return d.astype(np.uint16), c.astype(np.uint8), "OSD RGB-D frames (data/osd), 640x480"
         workload = "synthetic640"
-    from imagesegmentation_amd.synth import make_batch, make_mosaic_scene
+    from imagesegmentation_amd.synth import make_batch, make_dense_scene, make_mosaic_scene
+    if workload == "dense1280":
+        good = [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]          # seeds whose blocks of facets find room in the frame
+        d, c = zip(*(make_dense_scene(good[(rank + i) % len(good)], 960, 1280) for i in range(count)))
+        return np.stack(d), np.stack(c), "synthetic seeded 1280x960 scenes with about 420 surfaces close together (make_dense_scene)"
     if workload == "mosaic1280":
         seeds = [2 + 100 * rank + i for i in range(count)]
         d, c = zip(*(make_mosaic_scene(s, 960, 1280, labels - 2) for s in seeds))
@@ -127,8 +132,10 @@ def executed_work(ctx, depth, S, r):
     px = th * tw
     flops = (work * px * kk * (SIM_FLOPS * chunks + 2 * staged)).sum() / n
     q_bytes = (work * px * 4 * CE * 2).sum() / n + H * W * 28.0            # read + write of the carried planes, features, patch label
+    pct = [int(v) for v in np.percentile(CE[work], [50, 90, 99])] if work.any() else [0, 0, 0]
     info = {"tiles_per_frame": int(tx * ty), "tile": [th, tw], "tiles_skipped_frac": float(1 - work.mean()),
             "channels_per_tile_mean": float(CE[work].mean()) if work.any() else 0.0, "channels_per_tile_max": int(CE.max()),
+            "channels_per_tile_p50_p90_p99": pct,
             "chunks_per_tile_mean": float(chunks[work].mean()) if work.any() else 0.0}
     return float(flops), float(q_bytes), info
 
@@ -154,7 +161,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="osd", choices=["osd", "synthetic640", "synthetic1280", "mosaic1280", "stream640"])
+    ap.add_argument("--workload", default="osd", choices=["osd", "synthetic640", "synthetic1280", "mosaic1280", "dense1280", "stream640"])
     ap.add_argument("--stage", default="find_surfaces", choices=["find_surfaces", "stats"])
     ap.add_argument("--frames", type=int, default=0, help="frames per step and GPU (default 111; 16 for 1280x960; 100 for the stream)")
     ap.add_argument("--kernel-size", type=int, default=7)
@@ -162,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-buffer to host-buffer measurement after the headline loop")
+    ap.add_argument("--no-stats-leg", action="store_true", help="skip the statistics-stage measurement after the headline loop")
     ap.add_argument("--host-buffers", action="store_true",
                     help="time the host-pointer entry point as the main loop (what --workload stream640 implies)")
     args = ap.parse_args()
@@ -179,6 +187,11 @@ def main():
         from oracle import oracle as O
         O.build()                       # make runs as a child process: before anything touches the GPU
 
+    # before anything touches the GPU: this rank's threads (and with them its page-locked buffers) go to the CPUs of the
+    # NUMA node its GPU hangs on; N ranks that each move 17.5 MB per frame over PCIe otherwise meet on one socket
+    from imagesegmentation_amd.sharding import pin_to_gpu_numa_node
+    pinning = pin_to_gpu_numa_node(int(os.environ.get("FS_DEVICE", local_rank)))
+
     import torch
     import torch.distributed as dist
     # FS_DEVICE / FS_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with one card (all ranks share it and
@@ -194,7 +207,7 @@ def main():
             dist.init_process_group(backend)
 
     big = args.workload in ("synthetic1280", "mosaic1280")
-    frames = args.frames or (16 if big else 100 if args.workload == "stream640" else 111)
+    frames = args.frames or (16 if big else 4 if args.workload == "dense1280" else 100 if args.workload == "stream640" else 111)
     host_main = args.host_buffers or args.workload == "stream640"
     depth, rgb, data_desc = load_frames(args.workload, frames, rank, world, args.labels)
     n, H, W = depth.shape
@@ -266,16 +279,45 @@ def main():
         for _ in range(hs):
             step_host()
         barrier()
-        hdt = time.perf_counter() - t1
+        hdt_own = time.perf_counter() - t1                # this rank's own loop, before the barrier's wait for the slowest
+        per_rank = [n * hs / hdt_own]
         if world > 1:
-            t = torch.tensor([hdt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            hdt = float(t.item())
+            t = torch.tensor([hdt_own], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [n * hs / float(e.item()) for e in every]
+            hdt = max(float(e.item()) for e in every)
+        else:
+            hdt = hdt_own
         per_frame_bytes = H * W * (2 + 3) + H * W * (8 + 12 + 12 + 8 + 4 + 8)
         host_leg = {"value": world * n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
                     "bytes_per_frame": per_frame_bytes, "pcie_gbs": hs * world * n * per_frame_bytes / hdt / 1e9,
+                    "per_rank_images_per_s": per_rank,
                     "note": "page-locked host arrays in, six page-locked output arrays back; measured after the headline loop on "
-                            "all ranks at once (whole-job rate, max time over ranks)"}
+                            "all ranks at once (whole-job rate = frames of all ranks / the slowest rank's time; per_rank = each "
+                            "rank's own rate while the others ran: where they differ, ranks compete for the host)"}
+
+    stream_leg = None
+    if world > 1 and host_leg is not None and (H, W) == (480, 640):
+        # N > 1 only: the synthetic frame stream of the multi-GPU configuration (frame id % n_gpu == rank), host buffer to
+        # host buffer like the leg above, so that a scaling run shows it beside the HBM-resident headline
+        sd, sc, _ = load_frames("stream640", min(n, 32), rank, world, args.labels)
+        psd, psc = pinned_empty(sd.shape, np.uint16), pinned_empty(sc.shape, np.uint8)
+        psd[...] = sd
+        psc[...] = sc
+        sout = ctx.find_surfaces_batch(psd, psc)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            sout = ctx.find_surfaces_batch(psd, psc, out=sout)
+        own = time.perf_counter() - t2
+        t = torch.tensor([own], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        times = [float(e.item()) for e in every]
+        stream_leg = {"value": world * len(sd) * 3 / max(times), "unit": "images/s", "frames_per_rank_and_step": int(len(sd)), "steps": 3,
+                      "per_rank_images_per_s": [len(sd) * 3 / v for v in times],
+                      "note": "seeded synthetic 640x480 stream, frame id % n_gpu == rank, page-locked host buffers in and out"}
 
     if rank == 0:
         S = ns.astype(np.int64) + 1                       # label channels per frame
@@ -313,7 +355,9 @@ def main():
             traffic, busy, src = committed_counters(args.workload, r)
             out["roofline"] = {
                 "bound": "hbm", "limiter": "valu",
-                "kernel": "crf_iter_fused_kernel (mean-field update, similarity evaluated in the kernel)",
+                "kernel": ("crf_iter_fused_kernel<7> (mean-field update, similarity evaluated in the kernel, tile and halo in LDS)" if r == 7 else
+                           f"crf_iter_roll_kernel<{r if r in (10, 15) else 0}> (mean-field update, similarity evaluated in the kernel, "
+                           "window rolling through a 16-row ring in LDS)"),
                 "per": "one mean-field update of one frame",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes": total_bytes / updates,
@@ -325,12 +369,19 @@ def main():
                 "valu": {"achieved": ex_flops / (us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ex_flops / (us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, "busy": busy,
                          "algorithmic_tflops": alg_flops / sec / 1e12,
-                         "note": "executed fp32 flops: per tile, window positions x (45 similarity flops per 8-channel chunk + 2 per "
+                         "note": "executed fp32 flops: per tile, window positions x (33 similarity flops per 8-channel chunk + 2 per "
                                  "staged channel); algorithmic_tflops prices all S channels of every pixel and may exceed the peak "
                                  "because the kernel carries only the labels near a tile; busy = VALU-issue share of the kernel's "
                                  "duration from the committed SQ counters"}}
         if host_leg is not None:
             out["value_host_buffers"] = host_leg
+        if stream_leg is not None:
+            out["value_stream640"] = stream_leg
+        out["cpu_affinity"] = pinning
+        if world == 1 and not args.no_stats_leg and not host_main and args.workload == "osd":
+            # the stage that consumes these outputs (process_surfaces.py:672-689), batched on the frames still in HBM
+            from tools.bench_stats import stats_stage_summary
+            out["stats_stage"] = stats_stage_summary(ctx, torch, dev, ns, (d_rgb, d_angles, d_points, d_patches, d_edges, d_surfaces), H, W)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(depth, rgb, r)
             out["cpu_baseline_b0"] = cpu_baseline_b0(depth, rgb, r)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "fs_chi_squared_distances_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fs_overlap_counts": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "fs_nearest_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fs_set_debug_fill": (_i, [_vp, _c.c_char_p]),
     "fs_set_timing": (_i, [_vp, _i]),
     "fs_get_tile_labels": (_i, [_vp, _i, _vp] + [_c.POINTER(_i)] * 4),
     "fs_get_timing": (_i, [_vp, _i, _c.POINTER(_d), _c.POINTER(_c.c_int64)]),
@@ -346,6 +347,10 @@ class Context:
         allocates nothing, does not synchronise."""
         self._check(self._lib.fs_connected_components_noalloc(self._h, int(n), d_mask, int(min_size_exclusive), d_labels,
                                                               d_num_labels))
+
+    def set_debug_fill(self, letters):
+        """fs_set_debug_fill: work buffers to overwrite in front of every call ("" switches it off)."""
+        self._check(self._lib.fs_set_debug_fill(self._h, (letters or "").encode()))
 
     def synchronize(self):
         """Wait for the context's stream (fs_synchronize: the library's own HIP runtime does the waiting)."""

@@ -45,6 +45,7 @@ struct fs_ctx {
     // CRF buffers (one frame in flight)
     DevBuf simH, qa, qb, pot, unary, f1, f2, f3, rows, descs, featA, featB;
     DevBuf msg;                        // message planes of a wide update (one frame at a time)
+    std::string debug_fill;            // fs_set_debug_fill: work buffers to overwrite in front of every call (tests)
     HostBuf descs_host;                // page-locked staging of the frame descriptors; descs_copied: its last upload
     hipEvent_t descs_copied = nullptr;
     DevBuf crf_queue;                  // tile queues of the fused CRF update
@@ -186,15 +187,15 @@ int set_device(fs_ctx *ctx)
     return 0;
 }
 
-// FS_DEBUG_NAN=<letters>: float work buffers named by the letters are filled with NaN in front of every find_surfaces
+// fs_set_debug_fill(<letters>) (initially the value of FS_DEBUG_NAN): float work buffers named by the letters are filled with NaN in front of every find_surfaces
 // call (q: both sets of probability planes, a / b: the two halves of the feature records, s: smoothed depth, r: raw
 // angles; t: the tile records of the CRF update, as -1; p c n k u o m v e l: one integer work buffer each, as 1; w, read by the statistics stage: its work
 // arrays, as 1), so that
 // a kernel that reads a value nobody wrote in this call shows up in the results.
 int debug_nan_fill(fs_ctx *ctx)
 {
-    const char *which = getenv("FS_DEBUG_NAN");      // (read per call: a test switches it on and off)
-    if (!which || !*which) return 0;
+    if (ctx->debug_fill.empty()) return 0;
+    const char *which = ctx->debug_fill.c_str();
     auto fill = [&](DevBuf &b) -> hipError_t {
         return b.p ? hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.p), 0x7fc00000, b.cap / 4, ctx->stream) : hipSuccess;
     };
@@ -332,7 +333,8 @@ int ensure_frame_buffers(fs_ctx *ctx)
     ctx->queue_clean = false;
     FS_HIP(ctx->counts_host.ensure(2 * n * sizeof(int32_t)));
     if (!ctx->publish_seq.p) {
-        FS_HIP(ctx->publish_host.ensure(sizeof(unsigned long long)));
+        // (coherent: the GPU's store must become visible while the stream is still at work, whatever HIP_HOST_COHERENT says)
+        FS_HIP(ctx->publish_host.ensure(sizeof(unsigned long long), hipHostMallocCoherent));
         *ctx->publish_host.as<unsigned long long>() = 0;
         FS_HIP(ctx->publish_seq.ensure(sizeof(unsigned)));
         FS_HIP(hipMemset(ctx->publish_seq.p, 0, sizeof(unsigned)));
@@ -414,6 +416,9 @@ int wait_published_counts(fs_ctx *ctx)
     const unsigned long long want = ctx->publish_expected & 0xffffu;
     unsigned long long word;
     for (unsigned spins = 0; ((word = *pub) >> 48) != want; ++spins) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();                       // (a polling core leaves its sibling thread the execution units)
+#endif
         if ((spins & 0xffffu) != 0xffffu) continue;
         // now and then: is the stream still at work?  Once it has drained, the word is either there or will never come.
         const hipError_t e = hipStreamQuery(ctx->stream);
@@ -711,6 +716,7 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     ctx->stream = ctx->own_stream;
     if (hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(0); }
+    if (const char *e = getenv("FS_DEBUG_NAN")) ctx->debug_fill = e;          // (environment switches are read here, once)
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (const char *e = getenv("FS_NO_SPECULATION")) ctx->speculate = e[0] != '1';
     if (const char *e = getenv("FS_NO_EARLY_DOWNLOADS")) ctx->early_downloads = e[0] != '1';
@@ -858,6 +864,13 @@ int fs_synchronize(fs_ctx *ctx)
 }
 
 void *fs_stream(fs_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
+int fs_set_debug_fill(fs_ctx *ctx, const char *letters)
+{
+    if (!ctx) return -1;
+    ctx->debug_fill = letters ? letters : "";
+    return 0;
+}
 
 int fs_set_timing(fs_ctx *ctx, int enable)
 {
@@ -1442,7 +1455,7 @@ int surface_stats_core(fs_ctx *ctx, const char *who, int n, const int32_t *S, in
     w.ext_all = reinterpret_cast<uint32_t *>(ext);
     w.ext_words = tot.ext / 4;
     w.err = d_err;
-    if (const char *dbg = getenv("FS_DEBUG_NAN"); dbg && std::strchr(dbg, 'w')) {
+    if (ctx->debug_fill.find('w') != std::string::npos) {
         // the statistics stage's work arrays and the part of its scratch that no memset prepares, as 32-bit ones
         FS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->st_work.p), 1, ctx->st_work.cap / 4, ctx->stream));
         FS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(plain), 1, tot.plain / 4, ctx->stream));

@@ -62,11 +62,11 @@ struct DevBuf {
 struct HostBuf {
     void *p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t bytes)
+    hipError_t ensure(size_t bytes, unsigned flags = hipHostMallocDefault)
     {
         if (bytes <= cap) return hipSuccess;
         if (p) { hipError_t e = hipHostFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, bytes, flags);
         if (e == hipSuccess) cap = bytes;
         return e;
     }

@@ -5,7 +5,11 @@
 // allocator.  Inputs and outputs are the caller's device memory.
 //
 // One copy of the array exists per GPU, at its own address, for the life of the process.  Every call on a GPU
-// shares that GPU's copy: calls that overlap on one GPU (two streams, two threads) race; order them on one stream.
+// shares that GPU's copy.  Calls made through this entry point are ordered among themselves: each one makes its
+// stream wait for an event that the previous call on the same GPU recorded (created at set-up; waiting and
+// recording allocate nothing), so two contexts or threads on one GPU take turns instead of racing.  A stream under
+// capture cannot wait for an event recorded outside its capture: there the ordering is left out and overlapping
+// calls race, as they do with anything else that writes the caller's arrays.
 // The array keeps the previous call's contents; the kernels write every word they later read (parents and local
 // sizes of all pixels, counts at the roots, all block sums), so nothing has to be cleared between calls.
 #include <mutex>
@@ -26,7 +30,9 @@ static __device__ __align__(256) int32_t scratch[kNoallocInts];
 
 constexpr int kDevices = 64;
 int32_t *g_scratch_ptr[kDevices] = {};       // device address of `scratch` on each GPU (the array's name is not one)
+hipEvent_t g_scratch_free[kDevices] = {};    // recorded behind the last call that used the GPU's array
 std::mutex g_scratch_mutex;
+std::mutex g_call_mutex[kDevices];           // wait, launches and record of one call stay together
 
 }  // namespace
 
@@ -40,6 +46,10 @@ hipError_t noalloc_scratch_init(int device, int32_t **out)
         hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        g_scratch_free[device] = ev;
         g_scratch_ptr[device] = p;
     }
     if (out) *out = g_scratch_ptr[device];
@@ -63,8 +73,18 @@ hipError_t noalloc_connected_components(int device, const uint8_t *d_mask, int m
     w.newid = base + 2 * kNoallocMaxPixels;
     w.blocksum = base + 3 * kNoallocMaxPixels;
     w.nlabels = d_num_labels ? d_num_labels : base + 3 * kNoallocMaxPixels + kNoallocBlocks;   // n <= blocks
+    std::lock_guard<std::mutex> turn(g_call_mutex[device]);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+    const bool ordered = capturing == hipStreamCaptureStatusNone;
+    if (ordered) {
+        e = hipStreamWaitEvent(st, g_scratch_free[device], 0);      // the previous call on this GPU is done with the array
+        if (e != hipSuccess) return e;
+    }
     launch_connected_components(d_mask, w, min_size_exclusive, d_labels, nullptr, n, H, W, st);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e == hipSuccess && ordered) e = hipEventRecord(g_scratch_free[device], st);
+    return e;
 }
 
 }  // namespace fs

@@ -37,7 +37,8 @@ def sorted_alphanumeric(data):
 def _png_plain(path):
     """Decodes the plain kind of PNG the data set consists of (grey or RGB, 8 or 16 bits, not interlaced, rows filtered with
     None / Sub / Up) with zlib and numpy, which release the interpreter lock for the bulk of the work, so a pool of loader
-    threads scales (PIL holds the lock for most of a decode).  Returns None for any other file: the caller then uses PIL."""
+    threads scales (PIL holds the lock for most of a decode).  Returns None for any other file, 16-bit colour (which PIL
+    returns as 8 bits) and damaged streams included: the caller then uses PIL, which decides what such a file is."""
     with open(path, "rb") as f:
         b = f.read()
     if b[:8] != b"\x89PNG\r\n\x1a\n":
@@ -55,11 +56,14 @@ def _png_plain(path):
     if header is None:
         return None
     w, h, bits, colour, compression, filtering, interlace = header
-    if bits not in (8, 16) or colour not in (0, 2) or compression or filtering or interlace:
+    if bits not in (8, 16) or colour not in (0, 2) or compression or filtering or interlace or (bits == 16 and colour == 2):
         return None
     channels = 3 if colour == 2 else 1
     bpp = channels * bits // 8                      # bytes per pixel: the distance the Sub filter looks back
-    raw = np.frombuffer(zlib.decompress(b"".join(parts)), np.uint8)
+    try:
+        raw = np.frombuffer(zlib.decompress(b"".join(parts)), np.uint8)
+    except zlib.error:
+        return None
     if raw.size != h * (1 + w * bpp):
         return None
     raw = raw.reshape(h, 1 + w * bpp)

@@ -22,6 +22,70 @@ def shard(items, rank, world):
     return list(items)[rank::world]
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index, sysfs="/sys"):
+    """NUMA node of HIP device `device_index` from sysfs alone (no GPU call): the GPUs of the KFD topology in node order
+    are the runtime's device order (the entries of ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES select among them, when they
+    are plain indices); a node's location_id and domain give its PCI address, whose numa_node file names the node.
+    None when anything on the way is missing (no pinning is then the right answer)."""
+    try:
+        base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = {}
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    props[k] = v.strip()
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            sel = os.environ.get(var)
+            if sel:
+                gpus = [gpus[int(v)] for v in sel.split(",")]       # (UUID entries raise: no pinning)
+        props = gpus[device_index]
+        loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        with open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+
+
+def pin_to_gpu_numa_node(device_index, sysfs="/sys"):
+    """Restricts this process (threads started later inherit it) to the CPUs of the NUMA node its GPU hangs on, before the
+    first GPU call: a rank's page-locked buffers are then allocated on that node (first touch) and its copies do not
+    cross the socket interconnect, which is what bounds several ranks that each move 17 MB per frame over PCIe.
+    Returns a description of what was done; changes nothing when the node cannot be determined, when the node's CPUs
+    are not among those the process may use, or with FS_NO_NUMA_PINNING=1."""
+    if os.environ.get("FS_NO_NUMA_PINNING") == "1" or not hasattr(os, "sched_setaffinity"):
+        return {"numa_node": None, "pinned": False, "why": "switched off or unsupported"}
+    node = gpu_numa_node(device_index, sysfs)
+    if node is None:
+        return {"numa_node": None, "pinned": False, "why": "the GPU's NUMA node could not be read from sysfs"}
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        if not want:
+            return {"numa_node": node, "pinned": False, "why": "none of the node's CPUs is available to this process"}
+        os.sched_setaffinity(0, want)
+        return {"numa_node": node, "pinned": True, "cpus": len(want)}
+    except (OSError, ValueError):
+        return {"numa_node": node, "pinned": False, "why": "the node's CPU list could not be applied"}
+
+
 def run_sharded(image_indices, process, rank=None, world=None, gather=True):
     """Runs process(list_of_indices) -> dict on this rank's shard; returns the list of every
     rank's summary dict (on every rank) when torch.distributed is initialised and gather
@@ -46,7 +110,9 @@ def run_sharded(image_indices, process, rank=None, world=None, gather=True):
 def find_surfaces_for_indices_sharded(image_indices, mode="Gauss", kernel_size=7, save_data=True):
     """find_surfaces_for_indices over this rank's shard on GPU LOCAL_RANK."""
     from . import find_surfaces as fs
-    fs.set_device(int(os.environ.get("FS_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    device = int(os.environ.get("FS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    pin_to_gpu_numa_node(device)        # before the first GPU call: the context's page-locked buffers land on the GPU's node
+    fs.set_device(device)
 
     def process(indices):
         fs.find_surfaces_for_indices(indices, mode=mode, kernel_size=kernel_size, save_data=save_data)

@@ -121,3 +121,49 @@ def make_mosaic_scene(seed, height=960, width=1280, n_patches=30, noise_sigma=0.
     depth_u16 = np.round(depth).astype(np.uint16)
     depth_u16[~valid | (rng.random((H, W)) < 0.003)] = 0
     return depth_u16, np.clip(np.round(rgb), 0, 255).astype(np.uint8)
+
+
+def make_dense_scene(seed, height=960, width=1280, small=(15, 20), medium=(10, 12), noise_sigma=0.5):
+    """A scene with hundreds of small surfaces close together, so that the CRF's tiles see many labels each (the mosaic
+    scenes keep their facets in separate cells, and a tile sees four or five of them however many there are): a
+    block of small[0] x small[1] facets at a pitch of 20 pixels (2-pixel borders without depth between them: the
+    smallest facets the patch stage still turns into patches one for one) and a block of medium[0] x medium[1] facets
+    at a pitch of 48 pixels, both at seeded positions on a tilted background plane with elliptic holes; every facet a
+    tilted plane at a distance of its own.  With the defaults about 420 patches: 20 labels around a 32 x 16 tile of the
+    dense block at a window radius of 7, 30 at 10, 50 at 15.  Depth uint16 (0 = invalid), RGB = a base colour per
+    facet + N(0, 8)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    H, W = height, width
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = 2500 + 0.3 * (xx - W / 2) + 0.2 * (yy - H / 2)
+    rgb = rng.normal(90, 8, (H, W, 3)).astype(np.float32)
+    blocks = []
+    for (ny, nx), pitch, gap in ((small, 20, 2), (medium, 48, 3)):
+        bh, bw = ny * pitch, nx * pitch
+        for _ in range(1000):                                    # a position clear of the blocks placed so far
+            y0, x0 = int(rng.integers(8, H - bh - 8)), int(rng.integers(8, W - bw - 8))
+            if all(y0 + bh + 8 <= b[0] or b[1] + 8 <= y0 or x0 + bw + 8 <= b[2] or b[3] + 8 <= x0 for b in blocks):
+                break
+        else:
+            raise ValueError("the blocks of facets do not fit the frame")
+        blocks.append((y0, y0 + bh, x0, x0 + bw))
+        depth[y0:y0 + bh, x0:x0 + bw] = 0
+        levels = rng.permutation(np.linspace(800, 4600, ny * nx))
+        for k in range(ny * nx):
+            j, i = divmod(k, nx)
+            sl = np.s_[y0 + j * pitch + gap:y0 + (j + 1) * pitch - gap, x0 + i * pitch + gap:x0 + (i + 1) * pitch - gap]
+            depth[sl] = levels[k] + rng.uniform(-0.5, 0.5) * (xx[sl] - xx[sl].mean()) + rng.uniform(-0.5, 0.5) * (yy[sl] - yy[sl].mean())
+            rgb[sl] = rng.integers(20, 236, 3).astype(np.float32) + rng.normal(0, 8, depth[sl].shape + (3,)).astype(np.float32)
+    for _ in range(12):                                          # holes in the background plane
+        cy, cx = rng.uniform(0, H), rng.uniform(0, W)
+        hy, hx = rng.uniform(20, 70), rng.uniform(20, 70)
+        hole = ((yy - cy) / hy) ** 2 + ((xx - cx) / hx) ** 2 < 1
+        for b in blocks:
+            hole[max(b[0] - 8, 0):b[1] + 8, max(b[2] - 8, 0):b[3] + 8] = False
+        depth[hole] = 0
+    valid = depth > 0
+    if noise_sigma > 0:
+        depth = depth + rng.normal(0, noise_sigma, (H, W)).astype(np.float32)
+    depth_u16 = np.round(np.clip(depth, 500, 5000)).astype(np.uint16)
+    depth_u16[~valid | (rng.random((H, W)) < 0.003)] = 0
+    return depth_u16, np.clip(np.round(rgb), 0, 255).astype(np.uint8)

@@ -104,7 +104,10 @@ int fs_connected_components(fs_ctx *ctx, int n, const uint8_t *mask, int min_siz
  * stream without synchronising, and the work space is a static device array of the library (about 14 MiB per
  * GPU, held until the process ends) instead of the context's buffers: the call uses no hipMalloc / hipFree.
  * Limit: n * height * width <= fs_noalloc_max_pixels() (1280 * 960); larger calls fail with a message.
- * All calls on one GPU share that array: calls that overlap on one GPU (other streams, other contexts) race. */
+ * All calls on one GPU share that array.  The entry point orders them: a call's stream waits for the previous call on
+ * the same GPU (an event created with the first context; waiting and recording allocate nothing), so contexts and
+ * threads that share a GPU take turns.  On a stream under capture that ordering is left out, and calls that overlap on
+ * one GPU race. */
 int fs_connected_components_noalloc(fs_ctx *ctx, int n, const uint8_t *d_mask, int min_size_exclusive,
                                     int64_t *d_labels, int32_t *d_num_labels);
 size_t fs_noalloc_max_pixels(void);
@@ -272,6 +275,13 @@ int fs_overlap_counts(fs_ctx *ctx, const int64_t *annotation, const int64_t *det
  * result array. */
 int fs_nearest_points(fs_ctx *ctx, int groups, const float *points, const int32_t *point_offsets, const float *targets,
                       const int32_t *target_offsets, int32_t *out);
+
+/* Testing aid, no counterpart in the reference: the work buffers named by `letters` are overwritten in front of every
+ * later fs_find_surfaces_batch(_dev) / statistics call of this context (q a b s r: float buffers, as NaN; t: the CRF's
+ * tile records, as -1; p c n k u o m v e l w: integer work buffers, as 1), so that a kernel that uses a value the call has
+ * not written shows in the results.  NULL or "" switches it off.  A new context starts with the value of the
+ * environment variable FS_DEBUG_NAN, if set. */
+int fs_set_debug_fill(fs_ctx *ctx, const char *letters);
 
 /* ---- instrumentation -------------------------------------------------------
  * group_mask bit g set: HIP events are recorded on the context's stream around

@@ -215,11 +215,11 @@ def test_results_do_not_depend_on_what_the_work_buffers_held():
     with Context(H, W, max_batch=3) as ctx:
         ref_batch = ctx.find_surfaces_batch(d, c)
         ref_one = [ctx.find_surfaces_batch(d[i], c[i]) for i in range(3)]
-        os.environ["FS_DEBUG_NAN"] = "qabsrt"
+        ctx.set_debug_fill("qabsrt")
         try:
             for _ in range(2):
                 _same(ctx.find_surfaces_batch(d, c), ref_batch, "three frames")
                 for i in range(3):
                     _same(ctx.find_surfaces_batch(d[i], c[i]), ref_one[i], f"frame {i} alone")
         finally:
-            del os.environ["FS_DEBUG_NAN"]
+            ctx.set_debug_fill("")

@@ -48,27 +48,30 @@ def test_two_gpu_ranks_equal_one_process(tmp_path):
         assert np.array_equal(np.load(d / "depth.npy"), frames[k][0])
 
 
-@pytest.mark.parametrize("workload", ["osd", "stream640"])
-def test_bench_with_two_ranks(workload):
-    """bench.py's N > 1 path end to end: launched by torch.distributed.run as the driver launches it, two ranks, barriers on
-    both sides of the timed region, the maximum over ranks, one JSON line from rank 0.  One card here, so the ranks share
-    it and meet over gloo (FS_DEVICE / FS_BENCH_BACKEND); on a node the same code runs rank i on GPU i over RCCL."""
+@pytest.mark.parametrize("workload,world", [("osd", 2), ("stream640", 2), ("osd", 4)])
+def test_bench_with_several_ranks(workload, world):
+    """bench.py's N > 1 path end to end: launched by torch.distributed.run as the driver launches it, two or four ranks,
+    barriers on both sides of the timed region, the maximum over ranks, one JSON line from rank 0.  One card here, so the
+    ranks share it and meet over gloo (FS_DEVICE / FS_BENCH_BACKEND); on a node the same code runs rank i on GPU i over RCCL."""
     env = dict(os.environ, FS_DEVICE="0", FS_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--frames", "8", "--workload", workload]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     doc = json.loads(lines[0])
-    assert doc["n_gpus"] == 2 and doc["steps"] == 2 and doc["scaling"] == "weak"
-    assert doc["value"] > 0 and abs(doc["value"] - 2 * 8 * 2 / (doc["ms_per_step"] * 2e-3)) < 1e-6 * doc["value"]
+    assert doc["n_gpus"] == world and doc["steps"] == 2 and doc["scaling"] == "weak"
+    assert doc["value"] > 0 and abs(doc["value"] - world * 8 * 2 / (doc["ms_per_step"] * 2e-3)) < 1e-6 * doc["value"]
     assert "roofline" in doc and "cpu_baseline" not in doc
     # the host-buffer leg runs on all ranks at once after the headline loop (the stream workload is that leg already)
     assert ("value_host_buffers" in doc) == (workload == "osd")
     if workload == "osd":
-        assert doc["value_host_buffers"]["value"] > 0
-    print(f"{workload}: {doc['value']:.0f} images/s over two ranks on one card")
+        # ... with every rank's own rate beside the whole-job figure, and the synthetic stream of the multi-GPU configuration
+        assert doc["value_host_buffers"]["value"] > 0 and len(doc["value_host_buffers"]["per_rank_images_per_s"]) == world
+        assert doc["value_stream640"]["value"] > 0 and len(doc["value_stream640"]["per_rank_images_per_s"]) == world
+    assert "pinned" in doc["cpu_affinity"]
+    print(f"{workload}: {doc['value']:.0f} images/s over {world} ranks on one card")

@@ -150,6 +150,38 @@ def _declared_functions():
     return re.findall(r"\b(fs_[a-z_]+)\s*\(", src)
 
 
+def test_numa_pinning_reads_the_gpu_node_from_sysfs(tmp_path, monkeypatch):
+    """sharding.pin_to_gpu_numa_node on a made-up sysfs tree: two CPU nodes and two GPUs in the KFD topology, the second GPU on
+    NUMA node 1; device 1 is pinned to the CPUs of node 1 that the process may use, an unknown device changes nothing."""
+    from imagesegmentation_amd import sharding
+    nodes = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for i, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0500), (1024, 0x8500)]):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    for bdf, node in (("0000:05:00.0", 0), ("0000:85:00.0", 1)):
+        (tmp_path / "bus" / "pci" / "devices" / bdf).mkdir(parents=True)
+        (tmp_path / "bus" / "pci" / "devices" / bdf / "numa_node").write_text(f"{node}\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    for node, cpus in ((0, allowed[:half]), (1, allowed[half:] or allowed[:1])):
+        (tmp_path / "devices" / "system" / "node" / f"node{node}").mkdir(parents=True)
+        (tmp_path / "devices" / "system" / "node" / f"node{node}" / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "FS_NO_NUMA_PINNING"):
+        monkeypatch.delenv(var, raising=False)
+    assert sharding.gpu_numa_node(0, str(tmp_path)) == 0 and sharding.gpu_numa_node(1, str(tmp_path)) == 1
+    assert sharding.gpu_numa_node(2, str(tmp_path)) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert sharding.gpu_numa_node(0, str(tmp_path)) == 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    try:
+        assert sharding.pin_to_gpu_numa_node(5, str(tmp_path))["pinned"] is False and os.sched_getaffinity(0) == set(allowed)
+        res = sharding.pin_to_gpu_numa_node(1, str(tmp_path))
+        assert res["pinned"] and res["numa_node"] == 1 and os.sched_getaffinity(0) == set(allowed[half:] or allowed[:1])
+    finally:
+        os.sched_setaffinity(0, allowed)
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
 def test_library_exports_every_declared_symbol():
     from imagesegmentation_amd import _lib
     names = _declared_functions()
@@ -212,10 +244,12 @@ def test_bench_executed_work_model():
     depth[0, 16:, 32:] = 0                                   # the fourth tile has no valid depth
     flops, q_bytes, info = bench.executed_work(FakeCtx(), depth, np.array([20]), 7)
     # tiles: CE = 4 (1 chunk, 4 slots), 9 (2 chunks, 8 + 4 slots), 17 (3 chunks, 8 + 8 + 4 slots); S = 20 leaves unlisted labels
-    want = 512 * 224 * ((45 * 1 + 2 * 4) + (45 * 2 + 2 * 12) + (45 * 3 + 2 * 20))
+    sf = bench.SIM_FLOPS                                     # flops of one similarity (3 exponentials + 30)
+    want = 512 * 224 * ((sf * 1 + 2 * 4) + (sf * 2 + 2 * 12) + (sf * 3 + 2 * 20))
     assert flops == want
     assert q_bytes == 512 * 4 * 2 * (4 + 9 + 17) + 32 * 64 * 28.0
     assert info["tiles_skipped_frac"] == 0.25 and info["channels_per_tile_max"] == 17
+    assert info["channels_per_tile_p50_p90_p99"] == [9, 15, 16]
 
 
 def _write_png(path, img, filters):
@@ -277,6 +311,13 @@ def test_png_reader_equals_pil(tmp_path):
     Image.fromarray(noisy[..., 0]).convert("P").save(str(tmp_path / "pal.png"))
     assert L._png_plain(str(tmp_path / "pal.png")) is None
     assert np.array_equal(L.read_png(str(tmp_path / "pal.png")), np.asarray(Image.open(str(tmp_path / "pal.png"))))
+    # a damaged stream and 16-bit colour are left to PIL as well
+    good = open(str(tmp_path / "hand0.png"), "rb").read()
+    cut = good.index(b"IDAT") + 4
+    open(str(tmp_path / "broken.png"), "wb").write(good[:cut] + bytes(len(good) - cut))
+    assert L._png_plain(str(tmp_path / "broken.png")) is None
+    _write_png(str(tmp_path / "rgb16.png"), rng.integers(0, 65535, (9, 11, 3), endpoint=True).astype(np.uint16), [0] * 9)
+    assert L._png_plain(str(tmp_path / "rgb16.png")) is None
 
 
 def test_main_entry_point_runs_the_whole_data_set(monkeypatch):

@@ -21,6 +21,51 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
+def measure_batched(ctx, torch, dev, ns, tensors, H, W, steps, warmup):
+    """The batched statistics stage on device-resident outputs of find_surfaces (tensors: depth-independent inputs
+    d_rgb, d_angles, d_points, d_patches, d_edges, d_surfaces) -> (seconds for `steps` steps, algorithmic bytes per frame)."""
+    n, N = len(ns), H * W
+    d_rgb, d_angles, d_points, d_patches, d_edges, d_surfaces = tensors
+    t = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    el = [ctx.stats_output_elements(H, W, int(s)) for s in ns]
+    dts = {"surfaces": torch.int64, "patch_point_offsets": torch.int32, "patch_points": torch.float32, "avg_pos": torch.float64,
+           "counts": torch.float64, "centroids": torch.float32, "centroid_indices": torch.int32, "hist_color": torch.float64,
+           "hist_angle": torch.float64, "avg_angles": torch.float64, "neighbor_counts": torch.float64, "border_centers": torch.float64,
+           "norm": torch.float32, "depth_extend": torch.float32}
+    outs = {k: t((sum(e[k] for e in el),), dt) for k, dt in dts.items()}
+    ptrs = {k: v.data_ptr() for k, v in outs.items()}
+
+    def step():
+        ctx.surface_stats_batch_dev(ns, d_surfaces.data_ptr(), d_patches.data_ptr(), d_edges.data_ptr(), d_points.data_ptr(),
+                                    d_angles.data_ptr(), d_rgb=d_rgb.data_ptr(), **ptrs)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    S = ns.astype(np.int64)
+    # algorithmic bytes per frame: the seven input images once (int64 labels x2, int32 edges, 3-D points, angles, uint8 colours),
+    # the three image outputs (int64 labels, float2 point lists, float norm) and the float64 histograms [256][256][S] + [40][40][S]
+    alg = N * (8 + 8 + 4 + 12 + 8 + 3) + N * (8 + 8 + 4) + 8.0 * (65536 + 1600) * S
+    del outs
+    return dt, alg
+
+
+def stats_stage_summary(ctx, torch, dev, ns, tensors, H, W, steps=5, warmup=2):
+    """Short form for the default bench line: rate and roofline position of the batched statistics stage."""
+    dt, alg = measure_batched(ctx, torch, dev, ns, tensors, H, W, steps, warmup)
+    n = len(ns)
+    return {"metric": "surface statistics frames/sec (process_surfaces.py:672-689, batched, HBM-resident, uint8 colours converted on the device)",
+            "value": n * steps / dt, "unit": "frames/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "roofline": {"bound": "hbm", "per": "one frame", "achieved": float(alg.sum()) * steps / dt / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": float(alg.sum()) * steps / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": float(alg.mean()),
+                         "note": "host wall time of the batched call (15 kernels, one synchronisation), not a kernel duration"}}
+
+
 def main(args):
     from bench import load_frames
     want_cpu = not args.no_cpu_baseline
@@ -46,30 +91,8 @@ def main(args):
     ns = ctx.find_surfaces_batch_dev(n, d_depth.data_ptr(), d_rgb.data_ptr(), d_angles.data_ptr(), d_vectors.data_ptr(), d_points.data_ptr(),
                                      d_patches.data_ptr(), d_edges.data_ptr(), d_surfaces.data_ptr())
     torch.cuda.synchronize(dev)
-    el = [ctx.stats_output_elements(H, W, int(s)) for s in ns]
-    dts = {"surfaces": torch.int64, "patch_point_offsets": torch.int32, "patch_points": torch.float32, "avg_pos": torch.float64,
-           "counts": torch.float64, "centroids": torch.float32, "centroid_indices": torch.int32, "hist_color": torch.float64,
-           "hist_angle": torch.float64, "avg_angles": torch.float64, "neighbor_counts": torch.float64, "border_centers": torch.float64,
-           "norm": torch.float32, "depth_extend": torch.float32}
-    outs = {k: t((sum(e[k] for e in el),), dt) for k, dt in dts.items()}
-    ptrs = {k: v.data_ptr() for k, v in outs.items()}
-
-    def step():
-        ctx.surface_stats_batch_dev(ns, d_surfaces.data_ptr(), d_patches.data_ptr(), d_edges.data_ptr(), d_points.data_ptr(),
-                                    d_angles.data_ptr(), d_rgb=d_rgb.data_ptr(), **ptrs)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt, alg = measure_batched(ctx, torch, dev, ns, (d_rgb, d_angles, d_points, d_patches, d_edges, d_surfaces), H, W, args.steps, args.warmup)
     S = ns.astype(np.int64)
-    # algorithmic bytes per frame: the seven input images once (int64 labels x2, int32 edges, 3-D points, angles, uint8 colours),
-    # the three image outputs (int64 labels, float2 point lists, float norm) and the float64 histograms [256][256][S] + [40][40][S]
-    alg = N * (8 + 8 + 4 + 12 + 8 + 3) + N * (8 + 8 + 4) + 8.0 * (65536 + 1600) * S
     out = {"metric": "surface statistics frames/sec @640x480" if (H, W) == (480, 640) else f"surface statistics frames/sec @{W}x{H}",
            "value": n * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/f64",
