@@ -140,7 +140,7 @@ def executed_work(ctx, depth, S, r):
     return float(flops), float(q_bytes), info
 
 
-def committed_counters(workload, r):
+def committed_counters(workload, r, labels=None):
     """HBM bytes per frame-update and VALU busy fraction from the counter passes committed under profiles/ (rocprofv3
     --pmc runs cannot share a run with the timing)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
@@ -148,7 +148,7 @@ def committed_counters(workload, r):
         return None, None, None
     with open(files[-1]) as f:
         doc = json.load(f)
-    entry = doc.get("workloads", {}).get(f"{workload}_r{r}")
+    entry = doc.get("workloads", {}).get(f"{workload}_s{labels}_r{r}") or doc.get("workloads", {}).get(f"{workload}_r{r}")
     if entry is None and workload == "osd" and r == 7 and "hbm_bytes_per_frame_update" in doc:
         entry = doc
     if entry is None:
@@ -352,7 +352,7 @@ def main():
             nt = ((n - 1) % 16 + 1) if host_main else n
             ex_flops, ex_bytes, tiles = executed_work(ctx, depth[n - nt:], S[n - nt:], r)
             us = 1e6 * sec / updates
-            traffic, busy, src = committed_counters(args.workload, r)
+            traffic, busy, src = committed_counters(args.workload, r, args.labels)
             out["roofline"] = {
                 "bound": "hbm", "limiter": "valu",
                 "kernel": ("crf_iter_fused_kernel<7> (mean-field update, similarity evaluated in the kernel, tile and halo in LDS)" if r == 7 else

@@ -448,6 +448,8 @@ int ensure_sim(fs_ctx *ctx, size_t Npix, int Wimg, int frames, float **plane0, s
     return 0;
 }
 
+constexpr int kSpecLabels = 64;                // Q planes a one-frame call allocates before it knows the frame's label count
+constexpr int kSpecClass = 2;                  // kernel variant of the updates launched ahead of the counts (16 channels per tile)
 constexpr int kCrfGroup = 128;                 // most frames per batched CRF launch (few launches: each has a ramp and a tail)
 constexpr int kCrfGroupPlanes = 37;            // ... when the similarity planes of the group are kept as well
 constexpr size_t kCrfGroupBytes = (size_t)8 << 30;   // ... and most bytes of one Q buffer of a group
@@ -609,10 +611,28 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                     queue_slot = 0;
                 }
                 unsigned *queue = ctx->crf_queue.as<unsigned>() + (fused ? queue_slot++ : 0) * (kCrfQueueBytes / sizeof(unsigned));
+                // Frames whose fullest tile needs a variant with more than 16 channels: their other tiles (most of them, as a
+                // rule) go through the 16-channel variant, which is the fastest per tile, in a launch of its own; every launch
+                // walks all tiles of its frames and leaves alone those that list too many or too few labels for it.
+                // Only at r = 7, where the variants of the static-tile kernel differ most (the 32-channel one spills): 1280 x 960
+                // frames with 420 surfaces close together went from 449 to 338 us per update there, while the rolling kernels
+                // of r = 10 and 15 gained nothing from it (730 -> 725 us) or lost (1 690 -> 1 760 us).
+                const int small_max = 8 * kSpecClass - 3;          // listed labels + 3 channels fit the 16-channel variant
+                const bool split = fused && !trace && ctx->r == 7 && l.cls > kSpecClass && l.cls != kCrfWideClass;
                 hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, trace,
-                                                             l.wide_channels)
+                                                             l.wide_channels, split ? small_max + 1 : 0)
                                      : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
                 if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
+                if (split) {
+                    if (queue_slot == kCrfQueueSlots) {
+                        FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
+                        queue_slot = 0;
+                    }
+                    queue = ctx->crf_queue.as<unsigned>() + queue_slot++ * (kCrfQueueBytes / sizeof(unsigned));
+                    e = launch_crf_iter_fused(dd + l.first, l.count, kSpecClass, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, false, 0, 0,
+                                              small_max);
+                    if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
+                }
             }
         }
     }
@@ -620,8 +640,6 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
 }
 
 
-constexpr int kSpecLabels = 64;                // Q planes a one-frame call allocates before it knows the frame's label count
-constexpr int kSpecClass = 2;                  // kernel variant of the updates launched ahead of the counts (16 channels per tile)
 
 // does a frame with S label channels and max_active listed labels in its fullest tile fit a launch made ahead of the counts?
 bool spec_fits(int S, int max_active, int cap) { return S <= cap && crf_channel_class(std::min(S, max_active + 3)) == kSpecClass; }

@@ -282,6 +282,7 @@ constexpr int kCrfQueueSlots = 64;
 // with uniform window constants only)
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st,
-                                 bool trace = false, int wide_channels = 0);
+                                 bool trace = false, int wide_channels = 0, int a_min = 0, int a_max = 1 << 30);
+// a_min, a_max: the launch works on the tiles that list that many labels and skips the others (see FusedLaunch)
 
 }  // namespace fs

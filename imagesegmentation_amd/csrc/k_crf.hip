@@ -836,7 +836,7 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
 
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st, bool trace,
-                                 int wide_channels)
+                                 int wide_channels, int a_min, int a_max)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
@@ -854,6 +854,8 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     K.uw[3] = 0.0f;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
     FusedLaunch L{descs, nframes, g, K, wt, P.weight, first, last, tile_queue, st, trace};
+    L.a_min = a_min;
+    L.a_max = a_max;
     if (channel_class == kCrfWideClass) {
         // one pass per window of kMaxTileChannels channel slots, messages to descs[].msg, then the finishing kernel
         if (trace || wide_channels < 1) return hipErrorInvalidValue;

@@ -44,6 +44,9 @@ struct FusedLaunch {
     hipStream_t st;
     bool trace = false;      // the diagnostic kernels, which also write CrfFrameDesc::potentials and trace_q
     int c0 = 0;              // wide passes (launch_roll_wide): first channel slot of the pass
+    // the launch works on the tiles that list a_min .. a_max labels and leaves the others alone: a frame whose fullest
+    // tile needs a kernel variant with many channels runs its other tiles through the variant that fits them
+    int a_min = 0, a_max = 1 << 30;
 };
 // Instance files (k_crf_fused_*.hip): each compiles the kernel variants it names and returns
 // hipErrorInvalidValue for a combination it does not carry.

@@ -225,7 +225,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
 template <int R, int TH, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last,
-                                                             int nframes, unsigned *__restrict__ queue)
+                                                             int nframes, unsigned *__restrict__ queue, int a_min, int a_max)
 {
     constexpr int CH = 8;
     static_assert(TH == 16 || TH == 8, "tile height");
@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
     const int r = R ? R : g.r, S = frame_channels(d, NCH * CH);
-    if (S == 0) {                                            // enqueued ahead of the label count, and the frame does not fit
+    // (a tile outside the launch's range of listed labels belongs to another launch of the same update)
+    const int tile_labels = global_ptr(d.tile_recs)[((size_t)by * tiles_x + bx) * TILE_REC];
+    if (S == 0 || tile_labels < a_min || tile_labels > a_max) {   // S == 0: enqueued ahead of the label count, and the frame does not fit
         __syncthreads();                                     // (every lane has read the ticket)
         if (threadIdx.x == 0) s_ticket = claim_early ? next_ticket : next_tile();
         __syncthreads();
@@ -554,7 +556,7 @@ hipError_t launch_fused_t(const FusedLaunch &L)
     const unsigned nblk = (tiles + 7u) / 8u * 8u;
     constexpr unsigned max_blocks = 512u;
     dim3 grid(nblk < max_blocks ? nblk : max_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.a_min, L.a_max);
     return hipGetLastError();
 }
 

@@ -167,7 +167,7 @@ constexpr int roll_blocks_per_cu() { return (R > 0 && (FTW + 2 * R) * RING * 56 
 template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false>
 __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
-                                                            int nframes, unsigned *__restrict__ queue, int c0_arg)
+                                                            int nframes, unsigned *__restrict__ queue, int c0_arg, int a_min, int a_max)
 {
     constexpr int CH = 8, TH = RING;
     constexpr bool FOLD = UNIFORM && MODE == 0;
@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
     const int r = R ? R : g.r, S = WIDE ? d.S : frame_channels(d, NCH * CH);
-    if (S == 0) {                                            // enqueued ahead of the label count, and the frame does not fit
+    // (a tile outside the launch's range of listed labels belongs to another launch of the same update)
+    const int tile_labels = global_ptr(d.tile_recs)[((size_t)by * tiles_x + bx) * TILE_REC];
+    if (S == 0 || tile_labels < a_min || tile_labels > a_max) {   // S == 0: enqueued ahead of the label count, and the frame does not fit
         __syncthreads();                                     // (every lane has read the ticket)
         if (threadIdx.x == 0) s_ticket = claim_early ? next_ticket : next_tile();
         __syncthreads();
@@ -485,7 +487,7 @@ hipError_t launch_roll_t(const FusedLaunch &L)
     const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, as many as the chip holds at once
     const unsigned resident = 256u * roll_blocks_per_cu<R>();
     dim3 grid(nblk < resident ? nblk : resident);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.c0);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.c0, L.a_min, L.a_max);
     return hipGetLastError();
 }
 

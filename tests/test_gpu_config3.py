@@ -41,3 +41,43 @@ def test_synthetic_1280x960(k):
     assert not (dis & ~tie).any(), f"{int((dis & ~tie).sum())} label differences that are not numerical ties"
     assert agreement >= 0.999, agreement
     assert (got["surfaces"][d == 0] == 0).all()
+
+
+DENSE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dense1280.npz")
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_dense_1280x960(k, oracle):
+    """Frames with about 420 surfaces close together (imagesegmentation_amd.synth.make_dense_scene: 20 labels around a
+    tile of the dense block at r = 7, 30 at r = 10, 50 at r = 15; S is the frame's, as in the reference, where
+    find_surfaces.py:294 takes the channel count from the tensor), against tests/golden/dense1280.npz
+    (make_golden_dense1280.py): patches and edges bit-exact, labels differ only at the oracle's numerical ties and at
+    least 99.9 % are equal; then, on a window of the dense block, every update's softmax arguments and probabilities
+    against the oracle run on that window (the bounds of tests/test_gpu_crf_float.py)."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_dense_scene
+    from test_gpu_crf_float import _crop_check
+    g = np.load(DENSE)
+    seed, r = (int(v) for v in g["cases"][k])
+    d, c = make_dense_scene(seed, H, W)
+    assert zlib.crc32(d.tobytes()) == g[f"crc_depth_{k}"], "the generator no longer reproduces the fixture's frame"
+    with Context(H, W, max_batch=1, kernel_size=r) as ctx:
+        got = ctx.find_surfaces_batch(d, c)
+        listed = ctx.tile_labels(1)[0][0]
+        assert got["num_surfaces"] == g[f"num_surfaces_{k}"] and got["num_surfaces"] > 400
+        assert zlib.crc32(np.ascontiguousarray(got["patches"].astype(np.int32)).tobytes()) == g[f"crc_patches_{k}"]
+        assert zlib.crc32(np.ascontiguousarray(got["depth_edges"].astype(np.int8)).tobytes()) == g[f"crc_edges_{k}"]
+        dis = got["surfaces"] != g[f"surfaces_{k}"]
+        tie = np.unpackbits(g[f"near_tie_{k}"])[:dis.size].reshape(dis.shape).astype(bool)
+        agreement = 1.0 - dis.mean()
+        print(f"dense, S = {got['num_surfaces'] + 1}, r = {r}: label agreement {100 * agreement:.4f} %, {int(dis.sum())} differing pixels, "
+              f"most labels around a tile {int(listed.max())}")
+        assert not (dis & ~tie).any(), f"{int((dis & ~tie).sum())} label differences that are not numerical ties"
+        assert agreement >= 0.999, agreement
+        assert listed.max() >= (15, 25, 40)[k]                 # the scene is what it is meant to be: many labels per tile
+        # floating-point parity on a window around the tile that sees the most labels
+        ty, tx = np.unravel_index(int(np.argmax(listed)), listed.shape)
+        side = 96 + 6 * r
+        y0 = int(np.clip(ty * 16 + 8 - side // 2, 0, H - side))
+        x0 = int(np.clip(tx * 32 + 16 - side // 2, 0, W - side))
+        _crop_check(oracle, ctx, d, c, r, (y0, y0 + side, x0, x0 + side), f"dense 1280x960 r={r}")
