@@ -9,7 +9,10 @@
 // tools/run_variants.sh times the builds side by side; the product build defines none): FS_SKIPMAIN=1 drops the window
 // walk of the fused update, FS_SKIPSIM=1 only the similarity's arithmetic inside it, FS_SKIPQ=1 the staging of Q,
 // FS_SKIPFIN=1 the epilogue; FS_DEPTH_SERIES=0 evaluates the relative depth difference with a reciprocal per neighbour
-// instead of the series (see fused_accumulate).
+// instead of the series (see fused_accumulate); FS_CRF_MAX_BLOCKS=256u launches one block per CU.
+#ifndef FS_CRF_MAX_BLOCKS
+#define FS_CRF_MAX_BLOCKS 512u      // resident blocks of the r = 7 kernel: two per CU (256u: one per CU, one wave per SIMD)
+#endif
 #ifndef FS_DEPTH_SERIES
 #define FS_DEPTH_SERIES 1
 #endif

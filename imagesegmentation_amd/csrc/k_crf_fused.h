@@ -554,7 +554,7 @@ hipError_t launch_fused_t(const FusedLaunch &L)
     // several microseconds with half its waves missing; a block that just takes the next tile does not.
     if (!L.queue) return hipErrorInvalidValue;
     const unsigned nblk = (tiles + 7u) / 8u * 8u;
-    constexpr unsigned max_blocks = 512u;
+    constexpr unsigned max_blocks = FS_CRF_MAX_BLOCKS;
     dim3 grid(nblk < max_blocks ? nblk : max_blocks);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.a_min, L.a_max);
     return hipGetLastError();

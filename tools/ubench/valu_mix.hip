@@ -46,6 +46,17 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, float seed, in
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3),
                            "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
                          : "v"(c), "v"(d));
+        } else if (MODE == 5) {   // the walk's mix since the reciprocal went: 6 exponentials among 25 packed ops
+            asm volatile("v_exp_f32 %8, %8\n v_pk_fma_f32 %0, %0, %14, %15\n v_pk_fma_f32 %1, %1, %14, %15\n v_pk_fma_f32 %2, %2, %14, %15\n v_pk_fma_f32 %3, %3, %14, %15\n"
+                         "v_exp_f32 %9, %9\n v_pk_fma_f32 %4, %4, %14, %15\n v_pk_fma_f32 %5, %5, %14, %15\n v_pk_fma_f32 %6, %6, %14, %15\n v_pk_fma_f32 %7, %7, %14, %15\n"
+                         "v_exp_f32 %10, %10\n v_pk_fma_f32 %0, %0, %14, %15\n v_pk_fma_f32 %1, %1, %14, %15\n v_pk_fma_f32 %2, %2, %14, %15\n v_pk_fma_f32 %3, %3, %14, %15\n"
+                         "v_exp_f32 %11, %11\n v_pk_fma_f32 %4, %4, %14, %15\n v_pk_fma_f32 %5, %5, %14, %15\n v_pk_fma_f32 %6, %6, %14, %15\n v_pk_fma_f32 %7, %7, %14, %15\n"
+                         "v_exp_f32 %12, %12\n v_pk_fma_f32 %0, %0, %14, %15\n v_pk_fma_f32 %1, %1, %14, %15\n v_pk_fma_f32 %2, %2, %14, %15\n v_pk_fma_f32 %3, %3, %14, %15\n"
+                         "v_exp_f32 %13, %13\n v_pk_fma_f32 %4, %4, %14, %15\n v_pk_fma_f32 %5, %5, %14, %15\n v_pk_fma_f32 %6, %6, %14, %15\n v_pk_fma_f32 %7, %7, %14, %15\n"
+                         "v_pk_fma_f32 %0, %0, %14, %15"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3),
+                           "+v"(e4), "+v"(e5)
+                         : "v"(c), "v"(d));
         } else if (MODE == 4) {   // plain v_fma_f32 x 8
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                          "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
@@ -82,6 +93,7 @@ int main()
         run<0>("v_exp_f32 x8", 8, w);
         run<2>("walk mix, transcendentals spread (8 + 24 packed)", 32, w);
         run<3>("walk mix, transcendentals back to back", 32, w);
+        run<5>("walk mix without the reciprocals (6 + 25 packed)", 31, w);
     }
     return 0;
 }
