@@ -102,6 +102,20 @@ constexpr int MASK_WORDS = kMaxLabels / 32;
 constexpr int REC_MASK = 8, REC_LAB = REC_MASK + MASK_WORDS;
 constexpr int TILE_REC = REC_LAB + kMaxLabels;
 
+// Smallest label >= 1 whose bit is clear in a tile's label mask (MASK_WORDS words), found by 16 consecutive lanes of a
+// wave, one mask word each (lane16 = the lane's position in its group); every lane of the group gets the result, a large
+// number if every bit is set.
+static_assert(MASK_WORDS == 16, "one lane per mask word");
+__device__ __forceinline__ int first_unlisted_label(const int *mask, int lane16)
+{
+    unsigned w = ~(unsigned)mask[lane16];
+    if (lane16 == 0) w &= ~1u;                                   // label 0 does not count
+    int cand = w ? lane16 * 32 + __ffs((int)w) - 1 : 0x7fffffff;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 16));
+    return cand;
+}
+
 // Label channels of a frame for a kernel variant that carries at most `tile_channels` channels per tile; 0 when the
 // descriptor was written ahead of the label count (CrfFrameDesc::spec) and the frame turned out not to fit.
 __device__ __forceinline__ int frame_channels(const CrfFrameDesc &d, int tile_channels)

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         float4 fa[FU];
         float2 fb[FU];
         load_features(tid, fa, fb);
-        s_list[tid] = rec_word;
+        s_list[tid < REC_LAB ? tid : tid + 1] = rec_word;       // the labels one slot up: the list starts with label 0
         if (tid < 15 * MASK_WORDS) s_nmask[tid] = nb_word;
         store_features(tid, fa, fb);
     }
@@ -378,33 +378,34 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const bool block_work = __syncthreads_or(any_work) != 0;
 
     if (REC_LAB + listed_labels > 256) {                     // a label list longer than the first request (rare)
-        for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t] = rec[t];
+        for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t + 1] = rec[t];
         __syncthreads();
     }
-    // the rest of the features is on its way while one lane turns the record into the channel list
-    // [0, listed labels..., representative, S-1] and 15 lanes look up where to read each channel
+    // the rest of the features is on its way while the record becomes the channel list [0, listed labels...,
+    // representative, S-1] (sixteen lanes, one mask word each, find the representative) and the lanes below look up where to
+    // read each channel
     float4 fa2[FU];
     float2 fb2[FU];
     if (block_work) load_features(tid + 256 * FU, fa2, fb2);
-    if (tid == 0) {
+    if (tid < 16) {
         const int A = s_list[0];
-        int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
-        for (int i = A - 1; i >= 0; --i) labs[1 + i] = labs[i];
-        labs[0] = 0;
-        int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
-        if (n_rest > 0) {
-            int rp = 1;
-            while ((unsigned)m[rp >> 5] >> (rp & 31) & 1u) ++rp;   // smallest unlisted label in [1, S-2]
-            rep_pos = ce;
-            labs[ce++] = rp;
+        const int rep = first_unlisted_label(s_list + REC_MASK, tid);   // smallest unlisted label in [1, S-2] while one is left
+        if (tid == 0) {
+            int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
+            labs[0] = 0;
+            int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
+            if (n_rest > 0) {
+                rep_pos = ce;
+                labs[ce++] = rep;
+            }
+            labs[ce++] = S - 1;
+            // the slots that fill up the last group of four get a label no pixel carries: what the record held behind its
+            // labels (another tile's, another call's) must not pass for a pixel's own label where the groups are walked
+            for (int pad = ce; pad < ((ce + 3) & ~3); ++pad) labs[pad] = -2;
+            m[0] |= 1;
+            m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
+            s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
         }
-        labs[ce++] = S - 1;
-        // the slots that fill up the last group of four get a label no pixel carries: what the record held behind its
-        // labels (another tile's, another call's) must not pass for a pixel's own label where the groups are walked
-        for (int pad = ce; pad < ((ce + 3) & ~3); ++pad) labs[pad] = -2;
-        m[0] |= 1;
-        m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
-        s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
     }
     __syncthreads();
     const int CE = s_list[0];
@@ -417,21 +418,21 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                                  __uint_as_float(tid < CE ? (unsigned)s_list[REC_LAB + tid] * (unsigned)Ni : 0u));
     }
     // ---- where to read each of my channels in the 5x3 tiles the staged region touches ----
-    if (block_work && !first && tid < 15) {
-        const int sy = by + tid / 3 - 2, sx = bx + tid % 3 - 1;
+    if (block_work && !first && tid < 15 * 16) {                   // sixteen lanes per source tile
+        const int st = tid >> 4, c16 = tid & 15;
+        const int sy = by + st / 3 - 2, sx = bx + st % 3 - 1;
         const int CE8 = (CE + 7) & ~7;                              // the chunks are staged whole
-        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < CE8; ++c) s_src[tid][c] = kNoPlane;
-        } else {
-            const int32_t *m = s_nmask + tid * MASK_WORDS;
-            int rp = 1;                                             // representative of the source tile
-            while (rp < S - 1 && ((unsigned)m[rp >> 5] >> (rp & 31) & 1u)) ++rp;
-            for (int c = 0; c < CE; ++c) {
+        const bool outside = sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x;
+        const int32_t *m = s_nmask + st * MASK_WORDS;
+        const int rp = min(first_unlisted_label(m, c16), S - 1);    // representative of the source tile
+        for (int c = c16; c < CE8; c += 16) {
+            unsigned v = kNoPlane;
+            if (!outside && c < CE) {
                 const int l = s_list[REC_LAB + c];
                 const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = (unsigned)(listed ? l : rp) * (unsigned)Ni;
+                v = (unsigned)(listed ? l : rp) * (unsigned)Ni;
             }
-            for (int c = CE; c < CE8; ++c) s_src[tid][c] = kNoPlane;
+            s_src[st][c] = v;
         }
     }
     if (block_work) {

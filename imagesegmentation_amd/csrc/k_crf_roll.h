@@ -273,33 +273,33 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         const float2 b = global_load2(d.featB, p[1]);
         cd.y = a.x; cr.y = a.y; cg.y = a.z; cb.y = a.w; ca0.y = b.x; ca1.y = b.y;
     }
-    s_list[tid] = rec_word;
+    s_list[tid < REC_LAB ? tid : tid + 1] = rec_word;           // the labels one slot up: the list starts with label 0
     if (tid < 9 * MASK_WORDS) s_nmask[tid] = nb_word;
     const bool wave_work = __ballot(any_work) != 0ull;
     const bool block_work = __syncthreads_or(any_work) != 0;     // a tile without any valid depth only writes the override values
     if (REC_LAB + listed_labels > 256) {                     // a label list longer than the first request (rare)
-        for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t] = rec[t];
+        for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t + 1] = rec[t];
         __syncthreads();
     }
-    if (tid == 0) {                                          // channel list [0, listed labels..., representative, S-1]
+    if (tid < 16) {                                          // channel list [0, listed labels..., representative, S-1]
         const int A = s_list[0];
-        int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
-        for (int i = A - 1; i >= 0; --i) labs[1 + i] = labs[i];
-        labs[0] = 0;
-        int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
-        if (n_rest > 0) {
-            int rp = 1;
-            while ((unsigned)m[rp >> 5] >> (rp & 31) & 1u) ++rp;   // smallest unlisted label in [1, S-2]
-            rep_pos = ce;
-            labs[ce++] = rp;
+        const int rep = first_unlisted_label(s_list + REC_MASK, tid);   // smallest unlisted label in [1, S-2] while one is left
+        if (tid == 0) {
+            int *m = s_list + REC_MASK, *labs = s_list + REC_LAB;
+            labs[0] = 0;
+            int ce = A + 1, n_rest = (S - 2) - A, rep_pos = -1;
+            if (n_rest > 0) {
+                rep_pos = ce;
+                labs[ce++] = rep;
+            }
+            labs[ce++] = S - 1;
+            // the slots that fill up the last group of four get a label no pixel carries: what the record held behind its
+            // labels (another tile's, another call's) must not pass for a pixel's own label where the groups are walked
+            for (int pad = ce; pad < ((ce + 3) & ~3); ++pad) labs[pad] = -2;
+            m[0] |= 1;
+            m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
+            s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
         }
-        labs[ce++] = S - 1;
-        // the slots that fill up the last group of four get a label no pixel carries: what the record held behind its
-        // labels (another tile's, another call's) must not pass for a pixel's own label where the groups are walked
-        for (int pad = ce; pad < ((ce + 3) & ~3); ++pad) labs[pad] = -2;
-        m[0] |= 1;
-        m[(S - 1) >> 5] |= (int)(1u << ((S - 1) & 31));
-        s_list[0] = ce; s_list[1] = n_rest; s_list[2] = rep_pos;
     }
     __syncthreads();
     const int CE = s_list[0];
@@ -311,22 +311,22 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
                                  __uint_as_float(tid < CE ? (unsigned)s_list[REC_LAB + tid] * (unsigned)Ni : 0u));
     }
     // where to read each of my channels in the 3x3 tiles the region touches (r <= 15 < tile sides)
-    if (block_work && !first && tid < 9) {
-        const int sy = by + tid / 3 - 1, sx = bx + tid % 3 - 1;
+    if (block_work && !first && tid < 9 * 16) {                    // sixteen lanes per source tile
+        const int st = tid >> 4, c16 = tid & 15;
+        const int sy = by + st / 3 - 1, sx = bx + st % 3 - 1;
         const int slots = min(CE - c0, NCH * CH);                   // channel slots of this pass (all of them unless WIDE)
         const int slots8 = (slots + 7) & ~7;                        // the chunks are staged whole
-        if (sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x) {
-            for (int c = 0; c < slots8; ++c) s_src[tid][c] = kNoPlane;
-        } else {
-            const int32_t *m = s_nmask + tid * MASK_WORDS;
-            int rp = 1;                                             // representative of the source tile
-            while (rp < S - 1 && ((unsigned)m[rp >> 5] >> (rp & 31) & 1u)) ++rp;
-            for (int c = 0; c < slots; ++c) {
+        const bool outside = sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x;
+        const int32_t *m = s_nmask + st * MASK_WORDS;
+        const int rp = min(first_unlisted_label(m, c16), S - 1);    // representative of the source tile
+        for (int c = c16; c < slots8; c += 16) {
+            unsigned v = kNoPlane;
+            if (!outside && c < slots) {
                 const int l = s_list[REC_LAB + c0 + c];
                 const bool listed = l == 0 || l == S - 1 || ((unsigned)m[l >> 5] >> (l & 31) & 1u);
-                s_src[tid][c] = (unsigned)(listed ? l : rp) * (unsigned)Ni;
+                v = (unsigned)(listed ? l : rp) * (unsigned)Ni;
             }
-            for (int c = max(slots, 0); c < slots8; ++c) s_src[tid][c] = kNoPlane;
+            s_src[st][c] = v;
         }
     }
 
