@@ -57,7 +57,7 @@ def load_frames(workload, count, rank, world, labels):
         workload = "synthetic640"
     from imagesegmentation_amd.synth import make_batch, make_dense_scene, make_mosaic_scene
     if workload == "dense1280":
-        good = [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]          # seeds whose blocks of facets find room in the frame
+        good = [1, 2, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 18]          # seeds whose blocks of facets find room in the frame
         d, c = zip(*(make_dense_scene(good[(rank + i) % len(good)], 960, 1280) for i in range(count)))
         return np.stack(d), np.stack(c), "synthetic seeded 1280x960 scenes with about 420 surfaces close together (make_dense_scene)"
     if workload == "mosaic1280":
@@ -206,8 +206,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    big = args.workload in ("synthetic1280", "mosaic1280")
-    frames = args.frames or (16 if big else 4 if args.workload == "dense1280" else 100 if args.workload == "stream640" else 111)
+    big = args.workload in ("synthetic1280", "mosaic1280", "dense1280")
+    frames = args.frames or (16 if big else 100 if args.workload == "stream640" else 111)
     host_main = args.host_buffers or args.workload == "stream640"
     depth, rgb, data_desc = load_frames(args.workload, frames, rank, world, args.labels)
     n, H, W = depth.shape

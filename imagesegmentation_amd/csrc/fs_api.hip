@@ -49,6 +49,7 @@ struct fs_ctx {
     HostBuf descs_host;                // page-locked staging of the frame descriptors; descs_copied: its last upload
     hipEvent_t descs_copied = nullptr;
     DevBuf crf_queue;                  // tile queues of the fused CRF update
+    DevBuf tile_order;                 // sorted tile lists of the launches that want them (crf_tile_order_ints)
     bool queue_clean = false;          // all queue slots are zero and no launch has been given one since
     DevBuf curv_todo;                  // pixels whose curvature test needs the correctly rounded evaluation
     bool todo_clean = false;           // its per-frame counters are zero (the chain of kernels leaves them so)
@@ -452,7 +453,7 @@ constexpr int kSpecLabels = 64;                // Q planes a one-frame call allo
 constexpr int kSpecClass = 2;                  // kernel variant of the updates launched ahead of the counts (16 channels per tile)
 constexpr int kCrfGroup = 128;                 // most frames per batched CRF launch (few launches: each has a ramp and a tail)
 constexpr int kCrfGroupPlanes = 37;            // ... when the similarity planes of the group are kept as well
-constexpr size_t kCrfGroupBytes = (size_t)8 << 30;   // ... and most bytes of one Q buffer of a group
+constexpr size_t kCrfGroupBytes = (size_t)24 << 30;  // ... and most bytes of one Q buffer of a group (there are two)
 constexpr int kPipeChunk = 16;  // frames per upload / compute / download step of the host-buffer entry point
 
 // CRF of n frames resident on the device: similarity planes, initial probabilities from
@@ -481,19 +482,28 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     size_t qmax = 0;
     int gmax = 0;
     {
-        const int cap = fused ? kCrfGroup : kCrfGroupPlanes;
-        size_t q = 0;
-        for (int i = 0; i < n; ++i) {
-            const size_t qi = (size_t)S[i] * N;
-            if (i > gstart.back() && (i - gstart.back() == cap || (q + qi) * sizeof(float) > kCrfGroupBytes)) {
-                gstart.push_back(i);
-                q = 0;
+        // (two passes: the first counts the groups, the second deals the frames out evenly, so that the last group is not a
+        // small one whose launches leave most of the chip idle)
+        int cap = fused ? kCrfGroup : kCrfGroupPlanes;
+        for (int pass = 0; pass < 2; ++pass) {
+            gstart.assign(1, 0);
+            qmax = 0;
+            gmax = 0;
+            size_t q = 0;
+            for (int i = 0; i < n; ++i) {
+                const size_t qi = (size_t)S[i] * N;
+                if (i > gstart.back() && (i - gstart.back() == cap || (q + qi) * sizeof(float) > kCrfGroupBytes)) {
+                    gstart.push_back(i);
+                    q = 0;
+                }
+                q += qi;
+                if (q > qmax) qmax = q;
+                if (i + 1 - gstart.back() > gmax) gmax = i + 1 - gstart.back();
             }
-            q += qi;
-            if (q > qmax) qmax = q;
-            if (i + 1 - gstart.back() > gmax) gmax = i + 1 - gstart.back();
+            const int groups = (int)gstart.size();
+            gstart.push_back(n);
+            cap = std::min(cap, (n + groups - 1) / groups);
         }
-        gstart.push_back(n);
     }
     const int ngroups = (int)gstart.size() - 1;
     float *sim0 = nullptr;
@@ -501,6 +511,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     if (!fused && ensure_sim(ctx, N, W, gmax, &sim0, &sim_stride)) return -1;
     FS_HIP(ctx->qa.ensure(qmax * sizeof(float)));
     FS_HIP(ctx->qb.ensure(qmax * sizeof(float)));
+    if (fused) FS_HIP(ctx->tile_order.ensure(crf_tile_order_ints((size_t)tiles_x * tiles_y * gmax) * sizeof(int32_t)));
     const bool trace = ctx->trace_cap != 0;
     if (trace) {
         if (n != 1 || !fused) return ctx->fail("the diagnostic updates take one frame and the fused kernels");
@@ -520,7 +531,7 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
     FS_HIP(ctx->descs_host.ensure(ndesc * sizeof(CrfFrameDesc)));
     CrfFrameDesc *dh = ctx->descs_host.as<CrfFrameDesc>();
     std::fill(dh, dh + ndesc, CrfFrameDesc{});
-    struct Launch { size_t first; int count, cls, wide_channels; };
+    struct Launch { size_t first; int count, cls, wide_channels, max_listed; };
     size_t msg_floats = 0;                       // message planes of the largest wide frame
     std::vector<std::vector<Launch>> launches((size_t)ngroups * iterations);
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -569,9 +580,11 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
                 // registers) goes alone, because all of them use the context's one set of message planes in turn
                 const bool wide = cls[f] == kCrfWideClass;
                 if (k == 0 || cls[order[k]] != cls[order[k - 1]] || wide)
-                    launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f], wide ? std::min(S[fi], max_active[fi] + 3) : 0});
+                    launches[(size_t)gi * iterations + it].push_back(Launch{base + k, 1, cls[f], wide ? std::min(S[fi], max_active[fi] + 3) : 0, 0});
                 else
                     launches[(size_t)gi * iterations + it].back().count++;
+                Launch &lk = launches[(size_t)gi * iterations + it].back();
+                lk.max_listed = std::max(lk.max_listed, fused ? max_active[fi] : 0);
             }
         }
     }
@@ -606,31 +619,24 @@ int run_crf_batch(fs_ctx *ctx, int n, const uint16_t *d_depth, const uint8_t *d_
             ScopedTimer t(ctx, G_ITER);
             for (const Launch &l : launches[(size_t)gi * iterations + it]) {
                 const int mode = (it == iterations - 1 ? CRF_LAST : 0) | (it == 0 ? CRF_FIRST : 0);
-                if (fused && queue_slot == kCrfQueueSlots) {
-                    FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
-                    queue_slot = 0;
+                if (!fused) {
+                    const hipError_t e = launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
+                    if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
+                    continue;
                 }
-                unsigned *queue = ctx->crf_queue.as<unsigned>() + (fused ? queue_slot++ : 0) * (kCrfQueueBytes / sizeof(unsigned));
-                // Frames whose fullest tile needs a variant with more than 16 channels: their other tiles (most of them, as a
-                // rule) go through the 16-channel variant, which is the fastest per tile, in a launch of its own; every launch
-                // walks all tiles of its frames and leaves alone those that list too many or too few labels for it.
-                // Only at r = 7, where the variants of the static-tile kernel differ most (the 32-channel one spills): 1280 x 960
-                // frames with 420 surfaces close together went from 449 to 338 us per update there, while the rolling kernels
-                // of r = 10 and 15 gained nothing from it (730 -> 725 us) or lost (1 690 -> 1 760 us).
-                const int small_max = 8 * kSpecClass - 3;          // listed labels + 3 channels fit the 16-channel variant
-                const bool split = fused && !trace && ctx->r == 7 && l.cls > kSpecClass && l.cls != kCrfWideClass;
-                hipError_t e = fused ? launch_crf_iter_fused(dd + l.first, l.count, l.cls, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, trace,
-                                                             l.wide_channels, split ? small_max + 1 : 0)
-                                     : launch_crf_iter(dd + l.first, l.count, l.cls, geom, ctx->params.weight, ctx->params.evidence, mode, ctx->stream);
-                if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
-                if (split) {
+                // one launch, or one per group of tiles that share a kernel variant (crf_update_plan), each with its own queue
+                CrfSplit plan[kCrfMaxSplits];
+                const int nplan = crf_update_plan(ctx->params, ctx->r, l.cls, l.max_listed, trace, plan);
+                for (int s = 0; s < nplan; ++s) {
                     if (queue_slot == kCrfQueueSlots) {
                         FS_HIP(hipMemsetAsync(ctx->crf_queue.p, 0, kCrfQueueSlots * kCrfQueueBytes, ctx->stream));
                         queue_slot = 0;
                     }
-                    queue = ctx->crf_queue.as<unsigned>() + queue_slot++ * (kCrfQueueBytes / sizeof(unsigned));
-                    e = launch_crf_iter_fused(dd + l.first, l.count, kSpecClass, geom, ctx->params, ctx->wtab.as<float>(), mode, queue, ctx->stream, false, 0, 0,
-                                              small_max);
+                    unsigned *queue = ctx->crf_queue.as<unsigned>() + queue_slot++ * (kCrfQueueBytes / sizeof(unsigned));
+                    int32_t *order = nullptr;
+                    if (plan[s].channel_class & kCrfMultiClass) order = ctx->tile_order.as<int32_t>();
+                    const hipError_t e = launch_crf_iter_fused(dd + l.first, l.count, plan[s].channel_class, geom, ctx->params, ctx->wtab.as<float>(), mode, queue,
+                                                               ctx->stream, trace, l.wide_channels, plan[s].a_min, plan[s].a_max, order);
                     if (e != hipSuccess) return ctx->fail(e, "crf iteration launch");
                 }
             }
@@ -757,7 +763,7 @@ void fs_destroy(fs_ctx *ctx)
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin,
                       &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB, &ctx->msg};
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB, &ctx->msg, &ctx->tile_order};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

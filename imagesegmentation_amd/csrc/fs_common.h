@@ -94,6 +94,7 @@ constexpr int kMaxTileChannels = 128; // channels the update kernels carry per t
                                       // take one pass per 128 channels (kCrfWideClass); also the limit of fs_crf_step
 constexpr int kCrfWideClass = 1 << 10;   // crf_channel_class of such frames; launch_crf_iter_fused then wants wide_channels =
                                          // the most channels of a tile (descs[].msg must point at S label planes)
+constexpr int kCrfMultiClass = 1 << 11;  // | quads: the kernels that carry 4 * quads channels per walk of the window (see crf_update_plan)
 constexpr int kMaxRadius = 15;    // largest CRF window radius (kernel_size)
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----
@@ -282,7 +283,17 @@ constexpr int kCrfQueueSlots = 64;
 // with uniform window constants only)
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st,
-                                 bool trace = false, int wide_channels = 0, int a_min = 0, int a_max = 1 << 30);
+                                 bool trace = false, int wide_channels = 0, int a_min = 0, int a_max = 1 << 30, int32_t *tile_order = nullptr);
+// tile_order: device scratch of crf_tile_order_ints(tiles of the launch) ints for the launches that sort their tiles
+// (kCrfMultiClass), reusable by the next launch on the same stream
+size_t crf_tile_order_ints(size_t tiles);
 // a_min, a_max: the launch works on the tiles that list that many labels and skips the others (see FusedLaunch)
+// One update of frames of class channel_class (crf_channel_class of their fullest tile) as a sequence of launches, each
+// with the kernel variant that is fastest for the tiles it takes: out[i] = (class to launch, a_min, a_max); every launch
+// needs a tile queue of its own.  Returns the number of launches (1: no split).
+struct CrfSplit { int channel_class, a_min, a_max; };
+constexpr int kCrfMaxSplits = 4;
+// max_listed: most labels any tile of the frames lists (a launch for tiles beyond a variant's reach is left out when there are none)
+int crf_update_plan(const CrfParams &P, int r, int channel_class, int max_listed, bool trace, CrfSplit (&out)[kCrfMaxSplits]);
 
 }  // namespace fs

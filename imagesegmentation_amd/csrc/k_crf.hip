@@ -834,9 +834,76 @@ void launch_crf_pack_features(const uint16_t *depth, const uint8_t *rgb, const f
                        reinterpret_cast<float4 *>(featA), reinterpret_cast<float2 *>(featB), total, cs, as);
 }
 
+// The tiles of a launch that list a_min .. a_max labels, sorted by the number of walks of the window they take (walk_channels
+// channels per walk): order[0 .. 3] counts of the tiles with four (or more), three, two walks and one walk, then the four
+// lists, `total` entries apart.  Within a list the order is that of the atomic counter, which no result depends on.
+__global__ __launch_bounds__(256) void crf_tile_order_kernel(const CrfFrameDesc *__restrict__ descs, int tiles_per_frame, int total, int a_min,
+                                                             int a_max, int walk_channels, int32_t *__restrict__ order)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int bucket = -1;
+    if (t < total) {
+        const int bz = t / tiles_per_frame, rem = t - bz * tiles_per_frame;
+        const int A = descs[bz].tile_recs[(size_t)rem * TILE_REC];
+        if (A >= a_min && A <= a_max) {
+            const int walks = (A + 3 + walk_channels - 1) / walk_channels;
+            bucket = walks >= 4 ? 0 : 4 - walks;
+        }
+    }
+    // one atomic per wave and list: its tiles take consecutive places
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const unsigned long long m = __ballot(bucket == b);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(order + b, __popcll(m));
+        base = __shfl(base, leader);
+        if (bucket == b) order[4 + (size_t)b * total + base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    }
+}
+size_t crf_tile_order_ints(size_t tiles) { return 4 + 4 * tiles; }
+
+// the window's constants are uniform when the position terms vanish (as with the trained parameters)
+// and that variant also wants weights with a logarithm (non-negative) and no bias, as the loader of the
+// trained parameters guarantees (find_surfaces.py:221-226); anything else takes the table-driven kernels
+static bool crf_uniform(const CrfParams &P)
+{
+    return P.mode == 0 && P.t11 == 0.0f && P.t21 == 0.0f && P.t31 == 0.0f && P.w1 >= 0.0f && P.w2 >= 0.0f && P.w3 >= 0.0f && P.bias == 0.0f;
+}
+
+// A tile that lists A labels carries at most A + 3 channels (label 0, the representative of the unlisted labels, the
+// "unassigned" label).  Frames whose fullest tile needs a variant with more than 16 channels: their other tiles (most of
+// them, as a rule) go through the variant that is fastest for them, in a launch of its own; every launch walks all tiles
+// of its frames and leaves alone those that list too many or too few labels for it.
+//   r = 7: the static-tile kernel's 32-channel variant spills; 1280 x 960 frames with 420 surfaces close together went
+//          from 449 to 338 us per update with their tiles of up to 16 channels in the 16-channel variant.
+//   r = 10, 15 (trained parameters): tiles of 9 .. 64 channels take the kernels that evaluate the similarity once per
+//          window position for all their channels (k_crf_roll_m.hip), the rest the 8-channels-per-walk kernels.
+int crf_update_plan(const CrfParams &P, int r, int cls, int max_listed, bool trace, CrfSplit (&out)[kCrfMaxSplits])
+{
+    constexpr int all = 1 << 30;
+    out[0] = CrfSplit{cls, 0, all};
+    if (trace || cls <= 2 || cls == kCrfWideClass) return 1;
+    if (r == 7) {
+        out[0] = CrfSplit{cls, 14, all};
+        out[1] = CrfSplit{2, 0, 13};
+        return 2;
+    }
+    if ((r == 10 || r == 15) && crf_uniform(P)) {
+        int n = 0;
+        const int quads = r == 10 ? 4 : 3, most = 4 * 4 * quads - 3;               // four walks of 4 * quads channels
+        if (max_listed > most) out[n++] = CrfSplit{cls, most + 1, all};
+        out[n++] = CrfSplit{kCrfMultiClass | quads, 6, most};
+        out[n++] = CrfSplit{2, 0, 5};
+        return n;
+    }
+    return 1;
+}
+
 hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int channel_class, const CrfGeom &g,
                                  const CrfParams &P, const float *wtab, int mode, unsigned *tile_queue, hipStream_t st, bool trace,
-                                 int wide_channels, int a_min, int a_max)
+                                 int wide_channels, int a_min, int a_max, int32_t *tile_order)
 {
     if (g.r < 1 || g.r > kMaxRadius || nframes < 1) return hipErrorInvalidValue;
     const int last = (mode & CRF_LAST) ? 1 : 0, first = (mode & CRF_FIRST) ? 1 : 0;
@@ -845,11 +912,7 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
     FusedConsts K;
     K.K1 = (float)(144.0 * P.t12 * l2e); K.K2 = (float)(144.0 * P.t22 * l2e); K.K3 = (float)(144.0 * P.t32 * l2e);
     K.evidence = P.evidence;
-    // the window's constants are uniform when the position terms vanish (as with the trained parameters)
-    // and that variant also wants weights with a logarithm (non-negative) and no bias, as the loader of the
-    // trained parameters guarantees (find_surfaces.py:221-226); anything else takes the table-driven kernels
-    const bool uniform = P.mode == 0 && P.t11 == 0.0f && P.t21 == 0.0f && P.t31 == 0.0f && P.w1 >= 0.0f && P.w2 >= 0.0f &&
-                         P.w3 >= 0.0f && P.bias == 0.0f;
+    const bool uniform = crf_uniform(P);
     K.uw[0] = (float)-std::log2((double)P.w1); K.uw[1] = (float)-std::log2((double)P.w2); K.uw[2] = (float)-std::log2((double)P.w3);
     K.uw[3] = 0.0f;
     const float4 *wt = reinterpret_cast<const float4 *>(wtab);
@@ -873,6 +936,19 @@ hipError_t launch_crf_iter_fused(const CrfFrameDesc *descs, int nframes, int cha
         return hipGetLastError();
     }
     if (trace) return uniform ? launch_fused_trace(channel_class, L) : hipErrorInvalidValue;
+    if (channel_class & kCrfMultiClass) {
+        if (!uniform) return hipErrorInvalidValue;
+        const int quads = channel_class & 0xff;
+        if (tile_order) {
+            int tx, ty;
+            crf_fused_tile_grid(g.Hi, g.Wi, g.r, &tx, &ty);
+            const int total = tx * ty * nframes;
+            if (hipError_t e = hipMemsetAsync(tile_order, 0, 4 * sizeof(int32_t), st); e != hipSuccess) return e;
+            hipLaunchKernelGGL(crf_tile_order_kernel, dim3((total + 255) / 256), dim3(256), 0, st, descs, tx * ty, total, a_min, a_max, 4 * quads, tile_order);
+            L.order = tile_order;
+        }
+        return launch_roll_multi(quads, L);
+    }
     if (P.mode == 1) return launch_roll_table(2, channel_class, L);
     if (!uniform) return launch_roll_table(1, channel_class, L);
     // r = 7 keeps the tile with its whole halo in LDS (no step barriers, no half-idle first and last window row); a

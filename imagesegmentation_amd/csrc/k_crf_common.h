@@ -50,6 +50,9 @@ struct FusedLaunch {
     // the launch works on the tiles that list a_min .. a_max labels and leaves the others alone: a frame whose fullest
     // tile needs a kernel variant with many channels runs its other tiles through the variant that fits them
     int a_min = 0, a_max = 1 << 30;
+    // rolling kernels: the launch's tiles in the order to work on them, those that take the most walks of the window first
+    // (crf_tile_order_kernel: four counts, then four lists of `tiles` entries each); null: every tile, by number
+    const int32_t *order = nullptr;
 };
 // Instance files (k_crf_fused_*.hip): each compiles the kernel variants it names and returns
 // hipErrorInvalidValue for a combination it does not carry.
@@ -61,6 +64,9 @@ hipError_t launch_roll_table(int variant, int channel_class, const FusedLaunch &
 // one pass of a wide update (more channels per tile than kMaxTileChannels): the messages of channel slots
 // [L.c0, L.c0 + kMaxTileChannels) of every tile to descs[].msg; variant as above, any radius (k_crf_roll_t.hip)
 hipError_t launch_roll_wide(int variant, const FusedLaunch &L);
+// tiles with many labels around them, all channels of a walk fed by one evaluation of the similarity: `quads` quad planes
+// of Q in the ring; variant 0, r = 10 (quads 4, 8) and r = 15 (quads 3, 8) (k_crf_roll_m.hip)
+hipError_t launch_roll_multi(int quads, const FusedLaunch &L);
 // the same kernels built with their diagnostic outputs (variant 0 at any radius; k_crf_trace.hip)
 hipError_t launch_fused_trace(int channel_class, const FusedLaunch &L);
 

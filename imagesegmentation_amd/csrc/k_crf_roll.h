@@ -26,16 +26,20 @@ constexpr int RING = 16;                      // region rows resident in LDS = t
 // Similarity of the lane's two pixels to one neighbour each (a for pixel 0, b for pixel 1) and the message update.
 // Formulas and constants as in fused_accumulate (k_crf_fused.h): Gaussian kernels of find_surfaces.py:339-355 with the
 // normalisers and squared thetas folded into K and the stored features, or the linear similarity of :406-422.
-struct RollOperands { float4 fa; float2 fb; float4 q0, q1; };
+template <int NQ>
+struct RollOperands { float4 fa; float2 fb; float4 q[NQ]; };
 
-template <int NQ, int MODE, bool FOLD>
+template <int MODE, bool FOLD>
 struct PairSim {
     f2 cd, cr, cg, cb, ca0, ca1, cinv;
     f2 pB, pC, KA1, KA2, KA3;          // constants of the series for the squared relative depth difference (fused_accumulate)
     float K1, K2, K3;
 
-    __device__ __forceinline__ void step(f2 (&acc)[8], const RollOperands &a, const float4 &w0, const float4 &w1) const
+    // NQ quads of channels take the messages of this neighbour: the similarity is evaluated once however many there are
+    template <int NQ, int NACC>
+    __device__ __forceinline__ void step(f2 (&acc)[NACC], const RollOperands<NQ> &a, const float4 &w0, const float4 &w1) const
     {
+        static_assert(NACC >= 4 * NQ, "one accumulator pair per channel");
         const f2 dj = f2{a.fa.x, a.fa.x};
         const f2 e0 = f2{a.fa.y, a.fa.y} - cr, e1 = f2{a.fa.z, a.fa.z} - cg, e2 = f2{a.fa.w, a.fa.w} - cb;
         const f2 ec = __builtin_elementwise_fma(e2, e2, __builtin_elementwise_fma(e1, e1,
@@ -80,45 +84,48 @@ struct PairSim {
                  __builtin_elementwise_fma(f2{w0.y, w1.y}, sa,
                  __builtin_elementwise_fma(f2{w0.x, w1.x}, at, f2{w0.w, w1.w})));
         }
-        acc[0] = __builtin_elementwise_fma(sv, f2{a.q0.x, a.q0.x}, acc[0]);
-        acc[1] = __builtin_elementwise_fma(sv, f2{a.q0.y, a.q0.y}, acc[1]);
-        acc[2] = __builtin_elementwise_fma(sv, f2{a.q0.z, a.q0.z}, acc[2]);
-        acc[3] = __builtin_elementwise_fma(sv, f2{a.q0.w, a.q0.w}, acc[3]);
-        if (NQ > 1) {
-            acc[4] = __builtin_elementwise_fma(sv, f2{a.q1.x, a.q1.x}, acc[4]);
-            acc[5] = __builtin_elementwise_fma(sv, f2{a.q1.y, a.q1.y}, acc[5]);
-            acc[6] = __builtin_elementwise_fma(sv, f2{a.q1.z, a.q1.z}, acc[6]);
-            acc[7] = __builtin_elementwise_fma(sv, f2{a.q1.w, a.q1.w}, acc[7]);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            acc[4 * k + 0] = __builtin_elementwise_fma(sv, f2{a.q[k].x, a.q[k].x}, acc[4 * k + 0]);
+            acc[4 * k + 1] = __builtin_elementwise_fma(sv, f2{a.q[k].y, a.q[k].y}, acc[4 * k + 1]);
+            acc[4 * k + 2] = __builtin_elementwise_fma(sv, f2{a.q[k].z, a.q[k].z}, acc[4 * k + 2]);
+            acc[4 * k + 3] = __builtin_elementwise_fma(sv, f2{a.q[k].w, a.q[k].w}, acc[4 * k + 3]);
         }
     }
 };
 
 // One window row: the lane's pair against the 2r + 1 neighbours of ring row `slot`.  on0 / on1: whether pixel 0 /
 // pixel 1 has this row in its window; centre0 / centre1: whether it is the pixel's own row (its centre is excluded).
-template <int R, int NQ, int MODE, bool UNIFORM>
-__device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, UNIFORM && MODE == 0> &sim, const float4 *lds4, int plane4,
+// NQ: quads of channels read and accumulated; NQP: quad planes of the ring (the feature planes lie behind them).
+template <int R, int NQ, int NQP, int MODE, bool UNIFORM>
+__device__ __forceinline__ void roll_row(f2 (&acc)[NQP * 4], const PairSim<MODE, UNIFORM && MODE == 0> &sim, const float4 *lds4, int plane4,
                                          int rowbase, int r, bool on0, bool on1, bool centre0, bool centre1, const float4 &uon,
                                          const float4 *__restrict__ wrow0, const float4 *__restrict__ wrow1)
 {
+    static_assert(NQ <= NQP, "more quads than planes");
     const float kOff = __builtin_inff();
     const float4 uoff = make_float4(kOff, kOff, kOff, 0.0f);
     // one opaque LDS index per plane, so that every read of the row is base register + immediate
-    int iQ0 = rowbase, iQ1 = rowbase + plane4, iA = rowbase + 2 * plane4, iB = rowbase + 6 * plane4;
-    asm volatile("" : "+v"(iQ0), "+v"(iQ1), "+v"(iA), "+v"(iB));
-    const float4 *Q0 = lds4 + iQ0, *Q1 = lds4 + iQ1, *A = lds4 + iA;
+    int iQ[NQ], iA = rowbase + NQP * plane4, iB = rowbase + (NQP + 1) * 2 * plane4;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        iQ[k] = rowbase + k * plane4;
+        asm volatile("" : "+v"(iQ[k]));
+    }
+    asm volatile("" : "+v"(iA), "+v"(iB));
+    const float4 *A = lds4 + iA;
     const float2 *B = reinterpret_cast<const float2 *>(lds4) + iB;
     auto read = [&](int k) {
-        RollOperands o;
+        RollOperands<NQ> o;
         o.fa = A[k];
         o.fb = B[k];
-        o.q0 = Q0[k];
-        o.q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NQ > 1) o.q1 = Q1[k];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) o.q[j] = (lds4 + iQ[j])[k];
         return o;
     };
     const float4 row0 = on0 ? uon : uoff, row1 = on1 ? uon : uoff;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto position = [&](const RollOperands &o, int k) {
+    auto position = [&](const RollOperands<NQ> &o, int k) {
         float4 w0, w1;
         if (UNIFORM && MODE == 0) {
             w0 = row0; w1 = row1;
@@ -131,13 +138,13 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
             w0 = on0 ? wrow0[k] : zero4;
             w1 = on1 ? wrow1[k] : zero4;
         }
-        sim.step(acc, o, w0, w1);
+        sim.template step<NQ>(acc, o, w0, w1);
     };
-    RollOperands nxt = read(0);
+    RollOperands<NQ> nxt = read(0);
     if (R > 0) {
 #pragma unroll
         for (int k = 0; k <= 2 * R; ++k) {
-            const RollOperands o = nxt;
+            const RollOperands<NQ> o = nxt;
             if (k < 2 * R) nxt = read(k + 1);
             __builtin_amdgcn_sched_barrier(0);
             position(o, k);
@@ -146,7 +153,7 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
     } else {
 #pragma unroll 1
         for (int k = 0; k <= 2 * r; ++k) {
-            const RollOperands o = nxt;
+            const RollOperands<NQ> o = nxt;
             nxt = read(k < 2 * r ? k + 1 : k);
             __builtin_amdgcn_sched_barrier(0);
             position(o, k);
@@ -155,24 +162,37 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[8], const PairSim<NQ, MODE, U
     }
 }
 
-// blocks per CU the kernel is compiled for: three where the ring of three blocks fits the CU's 160 KB of LDS (the
-// kernel needs no more than the 168 registers that leaves a lane), else two
-template <int R>
-constexpr int roll_blocks_per_cu() { return (R > 0 && (FTW + 2 * R) * RING * 56 + 6 * 1024 <= 160 * 1024 / 3) ? 3 : 2; }
+// blocks per CU the kernel is compiled for: as many as rings (plus the 6 KB of tables a block keeps) fit the CU's 160 KB of
+// LDS, three at most (the kernel needs no more than the 168 registers that leaves a lane); a ring of NQP quad planes of Q
+// and the features takes 16 NQP + 24 bytes per pixel.  Run-time radius: sized for the largest one.
+template <int R, int NQP>
+constexpr int roll_blocks_per_cu()
+{
+    const int fit = 160 * 1024 / ((FTW + 2 * (R ? R : kMaxRadius)) * RING * (16 * NQP + 24) + 6 * 1024);
+    return R == 0 ? (fit >= 2 ? 2 : 1) : (fit >= 3 ? 3 : (fit >= 2 ? 2 : 1));
+}
 
 // WIDE: one pass of an update whose tiles carry more channels than a lane's registers hold (NCH * 8).  The pass works on
 // the channel slots [c0, c0 + NCH * 8) of every tile's list and, instead of finishing the update, leaves the raw messages
 // of those slots in descs[].msg (label planes like Q); the host runs one pass per window of slots and then
 // crf_wide_finish_kernel, which reads the messages back and does what finish_pair_compact does on registers.
-template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false>
-__global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
+//
+// NQP: quad planes of Q in the ring, i.e. NQP * 4 channels per walk of the window (NCH walks).  The similarity of a pixel
+// pair costs 20 packed and 6 transcendental instructions per window position, the messages 4 packed per quad of channels: a
+// tile with many labels around it is cheaper with all its channels in one walk (NQP = 3, 4 or 8, as many as the LDS holds
+// at that radius) than with 8 per walk and the similarity evaluated again in every walk.  The sums are the same numbers
+// either way (every channel adds its neighbours in window order).
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false, int NQP = 2>
+__global__ __launch_bounds__(256, (roll_blocks_per_cu<R, NQP>())) void crf_iter_roll_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                             const float4 *__restrict__ wtab, float weight, int first, int last,
-                                                            int nframes, unsigned *__restrict__ queue, int c0_arg, int a_min, int a_max)
+                                                            int nframes, unsigned *__restrict__ queue, int c0_arg, int a_min, int a_max,
+                                                            const int32_t *__restrict__ order)
 {
-    constexpr int CH = 8, TH = RING;
+    constexpr int CH = NQP * 4, TH = RING;
+    constexpr int NQLO = NQP == 2 ? 1 : NQP * 3 / 4;      // a walk reads NQLO or NQP quad planes
     constexpr bool FOLD = UNIFORM && MODE == 0;
     __shared__ unsigned s_ticket;
-    extern __shared__ float4 lds4[];          // ring: [2][RING][LW] Q quads | [RING][LW] (d,r,g,b) | [RING][LW] (a0,a1) as float2
+    extern __shared__ float4 lds4[];          // ring: [NQP][RING][LW] Q quads | [RING][LW] (d,r,g,b) | [RING][LW] (a0,a1) as float2
     __shared__ int s_list[TILE_REC + 8];      // (a list of every label, the representative's slot and the padding included)
     const int c0 = WIDE ? c0_arg : 0;         // first channel slot of this pass
     // where to read channel c in each of the 3x3 tiles the region touches: offset of the plane in Qin in elements
@@ -188,6 +208,18 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const unsigned per_xcd = (tiles_total + 7u) / 8u;
     unsigned qi = blockIdx.x & 7u, queues_left = 8;
     auto next_tile = [&]() -> unsigned {
+        if (order) {
+            // an ordered launch: one counter, four lists (tiles that take four walks of the window, three, two, one), so that
+            // the tiles that end the launch are the short ones
+            unsigned t = atomicAdd(queue, 1u);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned nb = (unsigned)order[b];
+                if (t < nb) return (unsigned)order[4 + b * tiles_total + t];
+                t -= nb;
+            }
+            return 0xffffffffu;
+        }
         while (queues_left) {
             const unsigned t = atomicAdd(queue + qi * (kCrfQueueStride / sizeof(unsigned)), 1u);
             const unsigned id = qi * per_xcd + t;
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const int Wi = g.Wi, Hi = g.Hi;
     const size_t Ni = (size_t)Hi * Wi;
     const int plane4 = RING * LW;
-    float4 *featA = lds4 + 2 * plane4;
+    float4 *featA = lds4 + NQP * plane4;
     float2 *featB = reinterpret_cast<float2 *>(featA + plane4);
     const int last_row = 2 * r + TH - 1;                     // region rows 0 .. last_row; region row y = frame row iy0 - r + y
 
@@ -315,11 +347,10 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
         const int st = tid >> 4, c16 = tid & 15;
         const int sy = by + st / 3 - 1, sx = bx + st % 3 - 1;
         const int slots = min(CE - c0, NCH * CH);                   // channel slots of this pass (all of them unless WIDE)
-        const int slots8 = (slots + 7) & ~7;                        // the chunks are staged whole
         const bool outside = sy < 0 || sy >= tiles_y || sx < 0 || sx >= tiles_x;
         const int32_t *m = s_nmask + st * MASK_WORDS;
         const int rp = min(first_unlisted_label(m, c16), S - 1);    // representative of the source tile
-        for (int c = c16; c < slots8; c += 16) {
+        for (int c = c16; c < NCH * CH; c += 16) {                  // (whole quads are staged: the rest reads as zeros)
             unsigned v = kNoPlane;
             if (!outside && c < slots) {
                 const int l = s_list[REC_LAB + c0 + c];
@@ -340,9 +371,9 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
     const float q_pv = (float)(1.0 / (double)ns), q_other = (float)(1.0 / (double)(ns - 1) * 0.1);
     __syncthreads();                                        // s_src, s_tab
 
-    // One pixel of a region row: features and the chunk's 8 (or 4) channels of Q, zero outside the frame.
+    // One pixel of a region row: features and the first nq quads of the walk's channels of Q, zero outside the frame.
     struct PixelRecord { float4 fa; float2 fb; float v[CH]; };
-    auto load_pixel = [&](int ch, bool upper, int row, int lx, bool want) {
+    auto load_pixel = [&](int ch, int nq, int row, int lx, bool want) {
         PixelRecord t;
         const int gy = iy0 - r + row, gxx = ix0 - r + lx;
         const bool in = want && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
@@ -358,49 +389,111 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 t.v[k] = 0.0f;
-                if (k < 4 || upper) {
+                if ((k >> 2) < nq) {
                     const int l = c0 + ch * CH + k < CE ? s_list[REC_LAB + c0 + ch * CH + k] : -1;
                     if (lab >= 0 && l > 0) t.v[k] = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
                 }
             }
         } else {
-            // one or two LDS reads for the planes of the pixel's channels, no wait between the loads of a pixel
+            // one LDS read per quad for the planes of the pixel's channels, no wait between the loads of a pixel
             const int st = in ? ((gy >> 4) - by + 1) * 3 + ((gxx >> 5) - bx + 1) : 0;
             const uint4 *src4 = reinterpret_cast<const uint4 *>(&s_src[st][ch * CH]);
             const uint4 none4 = make_uint4(kNoPlane, kNoPlane, kNoPlane, kNoPlane);
-            const uint4 o0 = in ? src4[0] : none4, o1 = (in && upper) ? src4[1] : none4;
-            const unsigned off[CH] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            unsigned off[CH];
+#pragma unroll
+            for (int j = 0; j < NQP; ++j) {
+                const uint4 o = (in && j < nq) ? src4[j] : none4;
+                off[4 * j] = o.x; off[4 * j + 1] = o.y; off[4 * j + 2] = o.z; off[4 * j + 3] = o.w;
+            }
             const gfloat *Qg = global_ptr(d.Qin);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 t.v[k] = 0.0f;
-                if (k < 4 || upper) {
+                if ((k >> 2) < nq) {
                     if (off[k] != kNoPlane) t.v[k] = Qg[off[k] + q];
                 }
             }
         }
         return t;
     };
-    auto store_pixel = [&](const PixelRecord &t, bool upper, int i) {
-        lds4[i] = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
-        if (upper) lds4[plane4 + i] = make_float4(t.v[4], t.v[5], t.v[6], t.v[7]);
+    auto store_pixel = [&](const PixelRecord &t, int nq, int i) {
+#pragma unroll
+        for (int j = 0; j < NQP; ++j)
+            if (j < nq) lds4[j * plane4 + i] = make_float4(t.v[4 * j], t.v[4 * j + 1], t.v[4 * j + 2], t.v[4 * j + 3]);
         featA[i] = t.fa;
         featB[i] = t.fb;
     };
 
-    PairSim<1, MODE, FOLD> sim1;
-    PairSim<2, MODE, FOLD> sim2;
-    sim1.K1 = sim2.K1 = K.K1; sim1.K2 = sim2.K2 = K.K2; sim1.K3 = sim2.K3 = K.K3;
-    sim1.cd = sim2.cd = cd; sim1.cr = sim2.cr = cr; sim1.cg = sim2.cg = cg; sim1.cb = sim2.cb = cb;
-    sim1.ca0 = sim2.ca0 = ca0; sim1.ca1 = sim2.ca1 = ca1;
-    sim1.cinv = sim2.cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
+    // The region row that enters the ring at every step of the walk comes in parts, one per wave: wave 0 requests the
+    // features of the row's pixels, quad j of the walk's channels is requested by wave (j + 1) & 3 (one lane per pixel).  Every
+    // wave then issues a quarter of the row's loads in front of its own arithmetic; with one wave loading the whole row the
+    // other three waited for it at the step's barrier.
+    constexpr int QPW = (NQP + 3) / 4;                    // quads of a wave's part
+    struct RowPart { float4 fa; float2 fb; float q[QPW][4]; };
+    const int my_quad = (wv + 3) & 3;                     // the wave's first quad (then every fourth)
+    auto load_part = [&](int ch, int nq, int row) {
+        RowPart t;
+        const int gy = iy0 - r + row, gxx = ix0 - r + lane;
+        const bool in = lane < LW && gy >= 0 && gy < Hi && gxx >= 0 && gxx < Wi;
+        const unsigned q = in ? (unsigned)gy * (unsigned)Wi + (unsigned)gxx : 0u;
+        t.fa = make_float4(0.f, 0.f, 0.f, 0.f);
+        t.fb = make_float2(0.f, 0.f);
+        if (wv == 0 && in) {
+            t.fa = global_load4(d.featA, q);
+            t.fb = global_load2(d.featB, q);
+        }
+        const int lab = (first && in) ? global_ptr(d.patches)[q] : -1;
+        const int st = in ? ((gy >> 4) - by + 1) * 3 + ((gxx >> 5) - bx + 1) : 0;
+        const gfloat *Qg = global_ptr(d.Qin);
+#pragma unroll
+        for (int k = 0; k < QPW; ++k) {
+            const int j = my_quad + 4 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.q[k][e] = 0.0f;
+            if (j < nq) {
+                if (first) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = c0 + ch * CH + 4 * j + e;
+                        const int l = c < CE ? s_list[REC_LAB + c] : -1;
+                        if (lab >= 0 && l > 0) t.q[k][e] = lab == 0 ? q_pv : (l == lab ? (float)0.9 : q_other);
+                    }
+                } else {
+                    const uint4 none4 = make_uint4(kNoPlane, kNoPlane, kNoPlane, kNoPlane);
+                    const uint4 o = in ? *reinterpret_cast<const uint4 *>(&s_src[st][ch * CH + 4 * j]) : none4;
+                    if (o.x != kNoPlane) t.q[k][0] = Qg[o.x + q];
+                    if (o.y != kNoPlane) t.q[k][1] = Qg[o.y + q];
+                    if (o.z != kNoPlane) t.q[k][2] = Qg[o.z + q];
+                    if (o.w != kNoPlane) t.q[k][3] = Qg[o.w + q];
+                }
+            }
+        }
+        return t;
+    };
+    auto store_part = [&](const RowPart &t, int nq, int i) {
+        if (wv == 0) {
+            featA[i] = t.fa;
+            featB[i] = t.fb;
+        }
+#pragma unroll
+        for (int k = 0; k < QPW; ++k) {
+            const int j = my_quad + 4 * k;
+            if (j < nq) lds4[j * plane4 + i] = make_float4(t.q[k][0], t.q[k][1], t.q[k][2], t.q[k][3]);
+        }
+    };
+
+    PairSim<MODE, FOLD> sim;
+    sim.K1 = K.K1; sim.K2 = K.K2; sim.K3 = K.K3;
+    sim.cd = cd; sim.cr = cr; sim.cg = cg; sim.cb = cb;
+    sim.ca0 = ca0; sim.ca1 = ca1;
+    sim.cinv = f2{cd.x == 0.0f ? 0.0f : 1.0f / cd.x, cd.y == 0.0f ? 0.0f : 1.0f / cd.y};
     {
         const f2 ha = f2{cd.x == 0.0f ? 0.0f : 0.5f / cd.x, cd.y == 0.0f ? 0.0f : 0.5f / cd.y}, ha2 = ha * ha;
-        sim1.pB = sim2.pB = ha * f2{-2.0f, -2.0f};
-        sim1.pC = sim2.pC = ha2 * f2{3.0f, 3.0f};
-        sim1.KA1 = sim2.KA1 = ha2 * f2{K.K1, K.K1};
-        sim1.KA2 = sim2.KA2 = ha2 * f2{K.K2, K.K2};
-        sim1.KA3 = sim2.KA3 = ha2 * f2{K.K3, K.K3};
+        sim.pB = ha * f2{-2.0f, -2.0f};
+        sim.pC = ha2 * f2{3.0f, 3.0f};
+        sim.KA1 = ha2 * f2{K.K1, K.K1};
+        sim.KA2 = ha2 * f2{K.K2, K.K2};
+        sim.KA3 = ha2 * f2{K.K3, K.K3};
     }
     const float4 uon = make_float4(K.uw[0], K.uw[1], K.uw[2], 0.0f);
     const int kw = 2 * r + 1;
@@ -408,36 +501,36 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (block_work && c0 + ch * CH < CE) {
-            const bool upper = CE - (c0 + ch * CH) > 4;      // channels 4..7 of the chunk are in use (uniform)
+            // quad planes this walk stages and reads (uniform): those in use, rounded up to a count the walk is compiled for
+            const int nq = ((CE - (c0 + ch * CH) + 3) >> 2) <= NQLO ? NQLO : NQP;
             if (ch > 0) __syncthreads();                     // the previous chunk's last row is read no more
             // ---- region rows 0 .. 15 fill the ring: flat index over 16 x LW pixels, two per thread and pass ----
             const int staged = RING * LW;
             for (int i0 = tid; i0 < staged; i0 += 512) {
                 const int i1 = i0 + 256;
                 const int y0 = i0 / LW, y1 = i1 / LW;
-                const PixelRecord t0 = load_pixel(ch, upper, y0, i0 - y0 * LW, true);
-                const PixelRecord t1 = load_pixel(ch, upper, y1, i1 - y1 * LW, i1 < staged);
-                store_pixel(t0, upper, i0);
-                if (i1 < staged) store_pixel(t1, upper, i1);
+                const PixelRecord t0 = load_pixel(ch, nq, y0, i0 - y0 * LW, true);
+                const PixelRecord t1 = load_pixel(ch, nq, y1, i1 - y1 * LW, i1 < staged);
+                store_pixel(t0, nq, i0);
+                if (i1 < staged) store_pixel(t1, nq, i1);
             }
             __syncthreads();
-            PixelRecord incoming;                            // the region row on its way from HBM (loader wave only)
+            RowPart incoming;                                // this wave's part of the region row on its way from HBM
             f2 cur[CH];                                      // this chunk's messages (acc[ch] is touched once, at the end)
 #pragma unroll
             for (int k = 0; k < CH; ++k) cur[k] = f2{0.0f, 0.0f};
             for (int s = 0; s <= 2 * r + 1; ++s) {
                 if (s > 0) __syncthreads();                  // every wave is done with region row s - 1
-                // loader duty: one wave per step, one lane per pixel of the row
-                if (s >= 1 && s + RING - 1 <= last_row && wv == ((s - 1) & 3) && lane < LW)
-                    store_pixel(incoming, upper, ((s - 1) & (RING - 1)) * LW + lane);
-                if (s + RING <= last_row && wv == (s & 3)) incoming = load_pixel(ch, upper, s + RING, lane, lane < LW);
+                // the row requested during the previous step takes the slot of the row that step was the last to read
+                if (s >= 1 && s + RING - 1 <= last_row && lane < LW) store_part(incoming, nq, ((s - 1) & (RING - 1)) * LW + lane);
+                if (s + RING <= last_row) incoming = load_part(ch, nq, s + RING);
                 if (!wave_work || FS_SKIPMAIN) continue;
                 __builtin_amdgcn_s_setprio(0);               // the arithmetic runs at low priority, staging at high
                 const int rowbase = ((trow + s) & (RING - 1)) * LW + col;
                 const bool on0 = s <= 2 * r, on1 = s >= 1;
                 const float4 *wrow0 = wtab + (on0 ? s : 0) * kw, *wrow1 = wtab + (on1 ? s - 1 : 0) * kw;
-                if (!upper) roll_row<R, 1, MODE, UNIFORM>(cur, sim1, lds4, plane4, rowbase, r, on0, on1, s == r, s == r + 1, uon, wrow0, wrow1);
-                else roll_row<R, 2, MODE, UNIFORM>(cur, sim2, lds4, plane4, rowbase, r, on0, on1, s == r, s == r + 1, uon, wrow0, wrow1);
+                if (nq == NQLO) roll_row<R, NQLO, NQP, MODE, UNIFORM>(cur, sim, lds4, plane4, rowbase, r, on0, on1, s == r, s == r + 1, uon, wrow0, wrow1);
+                else roll_row<R, NQP, NQP, MODE, UNIFORM>(cur, sim, lds4, plane4, rowbase, r, on0, on1, s == r, s == r + 1, uon, wrow0, wrow1);
                 __builtin_amdgcn_s_setprio(2);
             }
 #pragma unroll
@@ -473,21 +566,21 @@ __global__ __launch_bounds__(256, roll_blocks_per_cu<R>()) void crf_iter_roll_ke
   }
 }
 
-template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false>
+template <int R, int NCH, int MODE, bool UNIFORM, bool TRACE = false, bool WIDE = false, int NQP = 2>
 hipError_t launch_roll_t(const FusedLaunch &L)
 {
     static LdsAllowance allowed;
-    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM, TRACE, WIDE>;
+    auto kern = crf_iter_roll_kernel<R, NCH, MODE, UNIFORM, TRACE, WIDE, NQP>;
     const CrfGeom &g = L.g;
     if (R && g.r != R) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(FTW + 2 * g.r) * RING * (3 * sizeof(float4) + sizeof(float2));
+    const size_t lds = (size_t)(FTW + 2 * g.r) * RING * ((NQP + 1) * sizeof(float4) + sizeof(float2));
     if (hipError_t e = allowed.ensure(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     const unsigned tiles = (unsigned)((g.Wi + FTW - 1) / FTW) * ((g.Hi + RING - 1) / RING) * L.nframes;
     if (!L.queue) return hipErrorInvalidValue;
     const unsigned nblk = (tiles + 7u) / 8u * 8u;            // persistent blocks, as many as the chip holds at once
-    const unsigned resident = 256u * roll_blocks_per_cu<R>();
+    const unsigned resident = 256u * roll_blocks_per_cu<R, NQP>();
     dim3 grid(nblk < resident ? nblk : resident);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.c0, L.a_min, L.a_max);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.st, L.descs, g, L.K, L.wtab, L.weight, L.first, L.last, L.nframes, L.queue, L.c0, L.a_min, L.a_max, L.order);
     return hipGetLastError();
 }
 
