@@ -876,23 +876,25 @@ static bool crf_uniform(const CrfParams &P)
 // "unassigned" label).  Frames whose fullest tile needs a variant with more than 16 channels: their other tiles (most of
 // them, as a rule) go through the variant that is fastest for them, in a launch of its own; every launch walks all tiles
 // of its frames and leaves alone those that list too many or too few labels for it.
-//   r = 7: the static-tile kernel's 32-channel variant spills; 1280 x 960 frames with 420 surfaces close together went
-//          from 449 to 338 us per update with their tiles of up to 16 channels in the 16-channel variant.
-//   r = 10, 15 (trained parameters): tiles of 9 .. 64 channels take the kernels that evaluate the similarity once per
-//          window position for all their channels (k_crf_roll_m.hip), the rest the 8-channels-per-walk kernels.
+//   r = 7, 10, 15 with the trained parameters: tiles of 9 .. 64 channels (48 at r = 15) take the kernels that evaluate the
+//          similarity once per window position for 16 (12) channels (k_crf_roll_m.hip), the rest the 8-channels-per-walk
+//          kernels.  1280 x 960 frames with 420 surfaces close together: 449 -> 293 us per update at r = 7, 677 -> 467 at
+//          r = 10, 1 683 -> 1 176 at r = 15.
+//   r = 7, other parameter sets: the static-tile kernel's 32-channel variant spills, so tiles of up to 16 channels go
+//          through the 16-channel variant.
 int crf_update_plan(const CrfParams &P, int r, int cls, int max_listed, bool trace, CrfSplit (&out)[kCrfMaxSplits])
 {
     constexpr int all = 1 << 30;
     out[0] = CrfSplit{cls, 0, all};
     if (trace || cls <= 2 || cls == kCrfWideClass) return 1;
-    if (r == 7) {
+    if (r == 7 && !crf_uniform(P)) {
         out[0] = CrfSplit{cls, 14, all};
         out[1] = CrfSplit{2, 0, 13};
         return 2;
     }
-    if ((r == 10 || r == 15) && crf_uniform(P)) {
+    if ((r == 7 || r == 10 || r == 15) && crf_uniform(P)) {
         int n = 0;
-        const int quads = r == 10 ? 4 : 3, most = 4 * 4 * quads - 3;               // four walks of 4 * quads channels
+        const int quads = r == 15 ? 3 : 4, most = 4 * 4 * quads - 3;               // four walks of 4 * quads channels
         if (max_listed > most) out[n++] = CrfSplit{cls, most + 1, all};
         out[n++] = CrfSplit{kCrfMultiClass | quads, 6, most};
         out[n++] = CrfSplit{2, 0, 5};
