@@ -112,8 +112,11 @@ def cpu_baseline_b0(depth, rgb, r):
 
 def executed_work(ctx, depth, S, r):
     """What the CRF update executed in the last call, from the per-tile label lists the library keeps: a tile with A
-    listed labels carries CE = min(S, A + 3) channels (A + 2 when no unlisted label is left), in chunks of 8 whose
-    similarity is evaluated once per chunk, each chunk staging 4 or 8 channels.  Tiles without any valid depth are skipped.
+    listed labels carries CE = min(S, A + 3) channels (A + 2 when no unlisted label is left), in walks of the window whose
+    similarity is evaluated once per walk: 8 channels per walk (4 or 8 slots multiplied), or, for the tiles that list 6 or
+    more labels in a frame whose fullest tile lists more than 13 (r = 7, 10, 15 with the trained parameters:
+    crf_update_plan in csrc/k_crf.hip), 16 channels per walk (12 at r = 15; 12 or 16, 8 or 12 slots multiplied).  Tiles
+    without any valid depth are skipped.
     -> executed flops and compact Q bytes (planes a tile reads for its own pixels + planes it writes) per frame-update."""
     n, H, W = depth.shape
     listed, (th, tw) = ctx.tile_labels(n)
@@ -128,6 +131,14 @@ def executed_work(ctx, depth, S, r):
     CE = np.minimum(Sf, A + 2 + ((Sf - 2 - A) > 0))
     chunks = (CE + 7) // 8
     staged = 8 * (chunks - 1) + np.where(CE - 8 * (chunks - 1) > 4, 8, 4)    # channel slots multiplied per neighbour
+    if r in (7, 10, 15):
+        quads = 3 if r == 15 else 4
+        cw, lo = 4 * quads, 4 * (quads * 3 // 4)
+        many = (A.max(axis=(1, 2), keepdims=True) > 13) & (A >= 6) & (A <= 4 * cw - 3)
+        walks = (CE + cw - 1) // cw
+        last = CE - cw * (walks - 1)                                           # channels of the last walk
+        chunks = np.where(many, walks, chunks)
+        staged = np.where(many, cw * (walks - 1) + np.where(last > lo, cw, lo), staged)
     kk = (2 * r + 1) ** 2 - 1
     px = th * tw
     flops = (work * px * kk * (SIM_FLOPS * chunks + 2 * staged)).sum() / n
@@ -136,7 +147,9 @@ def executed_work(ctx, depth, S, r):
     info = {"tiles_per_frame": int(tx * ty), "tile": [th, tw], "tiles_skipped_frac": float(1 - work.mean()),
             "channels_per_tile_mean": float(CE[work].mean()) if work.any() else 0.0, "channels_per_tile_max": int(CE.max()),
             "channels_per_tile_p50_p90_p99": pct,
-            "chunks_per_tile_mean": float(chunks[work].mean()) if work.any() else 0.0}
+            "walks_per_tile_mean": float(chunks[work].mean()) if work.any() else 0.0}
+    if r in (7, 10, 15):
+        info["tiles_many_labels_frac"] = float((many & work).mean())          # share of the tiles that take the 12 / 16-channel walks
     return float(flops), float(q_bytes), info
 
 
@@ -355,9 +368,11 @@ def main():
             traffic, busy, src = committed_counters(args.workload, r, args.labels)
             out["roofline"] = {
                 "bound": "hbm", "limiter": "valu",
-                "kernel": ("crf_iter_fused_kernel<7> (mean-field update, similarity evaluated in the kernel, tile and halo in LDS)" if r == 7 else
-                           f"crf_iter_roll_kernel<{r if r in (10, 15) else 0}> (mean-field update, similarity evaluated in the kernel, "
-                           "window rolling through a 16-row ring in LDS)"),
+                "kernel": (("crf_iter_fused_kernel<7> (mean-field update, similarity evaluated in the kernel, tile and halo in LDS)" if r == 7 else
+                            f"crf_iter_roll_kernel<{r if r in (10, 15) else 0}> (mean-field update, similarity evaluated in the kernel, "
+                            "window rolling through a 16-row ring in LDS)")
+                           + (f" + crf_iter_roll_kernel<{r}, ..., {3 if r == 15 else 4}> for the tiles that list 6 or more labels "
+                              f"({12 if r == 15 else 16} channels per walk)" if tiles.get("tiles_many_labels_frac", 0) > 0 else "")),
                 "per": "one mean-field update of one frame",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes": total_bytes / updates,
@@ -369,8 +384,8 @@ def main():
                 "valu": {"achieved": ex_flops / (us * 1e-6) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ex_flops / (us * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, "busy": busy,
                          "algorithmic_tflops": alg_flops / sec / 1e12,
-                         "note": "executed fp32 flops: per tile, window positions x (33 similarity flops per 8-channel chunk + 2 per "
-                                 "staged channel); algorithmic_tflops prices all S channels of every pixel and may exceed the peak "
+                         "note": "executed fp32 flops: per tile, window positions x (33 similarity flops per walk of the window + 2 per "
+                                 "staged channel; 8 channels per walk, 16 or 12 for tiles with many labels); algorithmic_tflops prices all S channels of every pixel and may exceed the peak "
                                  "because the kernel carries only the labels near a tile; busy = VALU-issue share of the kernel's "
                                  "duration from the committed SQ counters"}}
         if host_leg is not None:

@@ -243,10 +243,14 @@ def test_bench_executed_work_model():
     depth = np.ones((1, 32, 64), np.uint16)
     depth[0, 16:, 32:] = 0                                   # the fourth tile has no valid depth
     flops, q_bytes, info = bench.executed_work(FakeCtx(), depth, np.array([20]), 7)
-    # tiles: CE = 4 (1 chunk, 4 slots), 9 (2 chunks, 8 + 4 slots), 17 (3 chunks, 8 + 8 + 4 slots); S = 20 leaves unlisted labels
+    # tiles: CE = 4 (1 walk, 4 slots), 9 and 17; S = 20 leaves unlisted labels.  The fullest tile lists more than 13 labels, so
+    # the tiles that list 6 or more take 16 channels per walk: 9 -> 1 walk with 12 slots, 17 -> 2 walks with 16 + 12 slots
     sf = bench.SIM_FLOPS                                     # flops of one similarity (3 exponentials + 30)
-    want = 512 * 224 * ((sf * 1 + 2 * 4) + (sf * 2 + 2 * 12) + (sf * 3 + 2 * 20))
+    want = 512 * 224 * ((sf * 1 + 2 * 4) + (sf * 1 + 2 * 12) + (sf * 2 + 2 * 28))
     assert flops == want
+    # another radius: 8 channels per walk throughout (9 -> 2 walks with 8 + 4 slots, 17 -> 3 walks with 8 + 8 + 4)
+    flops5, _, _ = bench.executed_work(FakeCtx(), depth, np.array([20]), 5)
+    assert flops5 == 512 * 120 * ((sf * 1 + 2 * 4) + (sf * 2 + 2 * 12) + (sf * 3 + 2 * 20))
     assert q_bytes == 512 * 4 * 2 * (4 + 9 + 17) + 32 * 64 * 28.0
     assert info["tiles_skipped_frac"] == 0.25 and info["channels_per_tile_max"] == 17
     assert info["channels_per_tile_p50_p90_p99"] == [9, 15, 16]

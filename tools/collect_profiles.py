@@ -53,8 +53,8 @@ def main():
     workloads = {}
     for key, pm, frames, kernel in (("osd_r7", "osd", 16, "crf_iter_fused_kernel"), ("mosaic1280_s32_r7", "m7", 4, "crf_iter_fused_kernel"),
                                     ("mosaic1280_s32_r10", "m10", 4, "crf_iter_roll_kernel"), ("mosaic1280_s64_r15", "m15", 4, "crf_iter_roll_kernel"),
-                                    ("dense1280_r7", "d7", 4, "crf_iter_fused_kernel"), ("dense1280_r10", "d10", 4, "crf_iter_roll_kernel"),
-                                    ("dense1280_r15", "d15", 4, "crf_iter_roll_kernel")):
+                                    ("dense1280_r7", "d7", 4, "crf_iter_"), ("dense1280_r10", "d10", 4, "crf_iter_"),
+                                    ("dense1280_r15", "d15", 4, "crf_iter_")):
         entry = {"frames_per_dispatch": frames, "kernel": kernel}
         c = {}
         calls = 2                                            # the counter passes run one warm-up and one timed step
