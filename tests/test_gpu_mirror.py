@@ -272,6 +272,34 @@ def test_more_channels_around_a_tile_than_the_kernels_keep_in_registers(oracle):
         assert (out != ref).mean() <= 0.0015
 
 
+@pytest.mark.parametrize("r,cells", [(7, 20), (7, 100), (10, 60), (10, 100), (15, 40), (15, 100)])
+def test_tiles_with_many_labels_take_their_own_launches(oracle, r, cells):
+    """A frame whose left part belongs to two large surfaces and whose right part is cut into `cells` labels in 2 x 2
+    cells: the tiles on the left list a few labels, those on the right all of them.  With the trained parameters at
+    r = 7, 10 and 15 an update of such a frame is several launches (the 8-channels-per-walk kernel for the tiles that list
+    up to 5 labels, 16 or 12 channels per walk for up to 61 or 45, the many-chunk variant beyond); the result is the
+    oracle's wherever its probabilities do not tie."""
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W = 64, 256
+    d, c = make_batch([17], H, W)
+    rng = np.random.default_rng(6)
+    ang = rng.normal(0, 0.3, (H, W, 2)).astype(np.float32)
+    labels = np.ones((H, W), np.int64)
+    labels[H // 2:, :128] = 2
+    grid = 3 + (np.arange(H // 2)[:, None] * 64 + np.arange(64)[None, :]) % cells
+    labels[:, 128:] = np.repeat(np.repeat(grid, 2, 0), 2, 1)
+    labels[20:30, 150:200] = 0                                # and a stretch that belongs to no surface
+    with Context(H, W, max_batch=1, kernel_size=r) as ctx:
+        out = ctx.apply_crf(labels, d[0], c[0], ang)
+        listed = ctx.tile_labels(1)[0][0]
+    assert (listed <= 5).any() and listed.max() >= cells, (listed.min(), listed.max())
+    ref, Q = _apply_crf_reference(oracle, labels, d[0], c[0], ang, r)
+    assert _ties_only(out, ref, Q)
+    print(f"r = {r}, {cells} labels on the right: tiles list {sorted(set(listed.ravel().tolist()))}, label disagreement {float((out != ref).mean()):.5f}")
+    assert (out != ref).mean() <= 0.0015
+
+
 def test_wide_frames_in_a_batch_with_ordinary_ones(oracle):
     """A batch that mixes a frame with more than 128 channels per tile with ordinary frames: every frame's result is
     what the frame gives alone (the wide frame takes launches of its own)."""
