@@ -6,9 +6,10 @@
 // region row by row, and at step s (s = 0 .. 2r+1) the 16 tile rows read only the region rows s .. s+15: a lane whose
 // pixel pair sits in tile rows (t, t+1) reads region row t + s, as neighbour row dy = s - r of its upper pixel and
 // dy = s - r - 1 of its lower one.  So the ring holds 16 region rows; after the barrier that ends step s - 1 the slot
-// of region row s - 1 is free and takes region row s + 15, which one wave requested from HBM during the previous
-// step.  LDS per block is 16 x (32 + 2r) x 56 bytes whatever the radius (41 KB at r = 7, 55 KB at r = 15): two blocks
-// per CU and full waves at every radius, for one barrier per window row.
+// of region row s - 1 is free and takes region row s + 15, which the block requested from HBM during the previous
+// step (every wave a part of it).  LDS per block is 16 x (32 + 2r) x 56 bytes whatever the radius (41 KB at r = 7, 55 KB
+// at r = 15) with two quad planes of Q in the ring: two blocks per CU and full waves at every radius, for one barrier per
+// window row.  Tiles with many labels use instantiations with three or four quad planes (12 or 16 channels per walk).
 //
 // Everything else is the static kernel's: 32 x 16 tiles, a lane owns two vertically adjacent pixels as packed pairs,
 // compact label planes, per-tile channel lists, persistent blocks on per-XCD tile queues.  At the first and the last
