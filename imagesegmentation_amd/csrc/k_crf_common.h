@@ -9,7 +9,9 @@
 // tools/run_variants.sh times the builds side by side; the product build defines none): FS_SKIPMAIN=1 drops the window
 // walk of the fused update, FS_SKIPSIM=1 only the similarity's arithmetic inside it, FS_SKIPQ=1 the staging of Q,
 // FS_SKIPFIN=1 the epilogue; FS_DEPTH_SERIES=0 evaluates the relative depth difference with a reciprocal per neighbour
-// instead of the series (see fused_accumulate); FS_CRF_MAX_BLOCKS=256u launches one block per CU.
+// instead of the series (see fused_accumulate); FS_CRF_MAX_BLOCKS=256u launches one block per CU;
+// FS_ASM_STEP=1 walks the shared rows with the hand-scheduled assembly of walk_similarity (same bits, same time as the
+// compiler's code: profiles/r3_walk_instruction_costs.txt), FS_ASM_ABL its ablations.
 #ifndef FS_CRF_MAX_BLOCKS
 #define FS_CRF_MAX_BLOCKS 512u      // resident blocks of the r = 7 kernel: two per CU (256u: one per CU, one wave per SIMD)
 #endif
@@ -27,6 +29,12 @@
 #endif
 #ifndef FS_SKIPMAIN
 #define FS_SKIPMAIN 0
+#endif
+#ifndef FS_ASM_STEP
+#define FS_ASM_STEP 1               // the shared rows of the r = 7 window walk in assembly (walk_similarity); 0: the compiler's code for step()
+#endif
+#ifndef FS_ASM_ABL
+#define FS_ASM_ABL 0                // with FS_ASM_STEP: 1 no exponentials, 2 no messages, 3 / 4 a v_mov / v_mul in place of each exponential
 #endif
 
 namespace fs {
