@@ -30,6 +30,9 @@
 #ifndef FS_SKIPMAIN
 #define FS_SKIPMAIN 0
 #endif
+#ifndef FS_TILE_CLOCKS
+#define FS_TILE_CLOCKS 0             // 1: per-phase cycle counts of the r = 7 kernel's tiles (fs_debug_phase_clocks)
+#endif
 #ifndef FS_ASM_STEP
 #define FS_ASM_STEP 1               // the shared rows of the r = 7 window walk in assembly (walk_similarity); 0: the compiler's code for step()
 #endif

@@ -365,6 +365,14 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     }
 }
 
+#if FS_TILE_CLOCKS
+// experiment build: cycles that the first lane of every block spent in the phases of the tiles it worked on
+// (fs_debug_phase_clocks in k_crf_fused_r7.hip reads and clears them; tools/phase_clocks.py)
+__device__ unsigned long long g_phase_clocks[8];
+#define FS_PHASE(i) do { if (threadIdx.x == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); ph[i] += t_now - t_last; t_last = t_now; } } while (0)
+#else
+#define FS_PHASE(i) do { } while (0)
+#endif
 template <int R, int TH, int NCH, int MODE, bool UNIFORM, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDesc *__restrict__ descs, CrfGeom g, FusedConsts K,
                                                              const float4 *__restrict__ wtab, float weight, int first, int last,
@@ -419,9 +427,15 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     }
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();
+#if FS_TILE_CLOCKS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+#endif
   for (;;) {
     const unsigned tile_id = s_ticket;
     if (tile_id == 0xffffffffu) break;
+#if FS_TILE_CLOCKS
+    t_last = __builtin_readcyclecounter();
+#endif
     if (claim_early && threadIdx.x == 0) next_ticket = next_tile();
     const int bz = tile_id / (tiles_x * tiles_y), brem = tile_id - bz * (tiles_x * tiles_y);
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
@@ -519,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     // a tile without a single valid depth (about one in five on sensor data) only writes the override values:
     // nothing more is staged for it
     const bool block_work = __syncthreads_or(any_work) != 0;
+    FS_PHASE(0);                                            // record, lane state, first half of the features
 
     if (REC_LAB + listed_labels > 256) {                     // a label list longer than the first request (rare)
         for (int t = 256 + tid; t < REC_LAB + listed_labels; t += 256) s_list[t + 1] = rec[t];
@@ -551,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         }
     }
     __syncthreads();
+    FS_PHASE(1);                                            // channel list
     const int CE = s_list[0];
 
     if (tid < NCH * CH) {
@@ -599,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int ns = S - 1;
     const float q_pv = (float)(1.0 / (double)ns), q_other = (float)(1.0 / (double)(ns - 1) * 0.1);
     __syncthreads();                                        // s_src, features
+    FS_PHASE(2);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (block_work && ch * CH < CE) {
@@ -653,6 +670,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
                 }
             }
             __syncthreads();
+            FS_PHASE(3);                                    // Q staged
             if (wave_work && FS_SKIPMAIN == 0) {
                 // The arithmetic runs at low priority, set-up, staging and epilogue at high priority: the
                 // few instructions between a tile's memory requests then do not queue behind the other
@@ -666,6 +684,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         }
     }
 
+    FS_PHASE(4);                                            // window walk (of the first wave)
     if (!claim_early && threadIdx.x == 0) next_ticket = next_tile();
     if (FS_SKIPFIN) {                              // timing experiments: keep the messages alive without the epilogue
         float t = 0.0f;
@@ -680,7 +699,15 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     }
     if (threadIdx.x == 0) s_ticket = next_ticket;     // every lane read the current ticket several barriers ago
     __syncthreads();                                  // the next tile reuses the LDS
+    FS_PHASE(5);                                      // epilogue
+#if FS_TILE_CLOCKS
+    if (threadIdx.x == 0) ph[6] += block_work ? 1 : 0, ph[7] += 1;
+#endif
   }
+#if FS_TILE_CLOCKS
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_clocks[i], ph[i]);
+#endif
 }
 template <int R, int TH, int NCH, int MODE, bool UNIFORM = false, bool TRACE = false>
 hipError_t launch_fused_t(const FusedLaunch &L)
