@@ -111,7 +111,107 @@ __device__ __forceinline__ float2 global_load2(const float2 *p, unsigned i)
     const f2 v = ((const __attribute__((address_space(1))) f2 *)p)[i];
     return make_float2(v.x, v.y);
 }
-constexpr unsigned kNoPlane = 0xffffffffu;   // s_src entry of a channel that reads zeros
+constexpr unsigned kNoPlane = 0xffffffffu;
+
+#if FS_ASM_STEP
+// One window position of a row that both pixels of a lane's pair see, in the instruction order it should issue in (Gaussian
+// similarity, weights folded into the exponents, depth series; the arithmetic is described at fused_accumulate in
+// k_crf_fused.h): the neighbour's record (fa01 = depth, r; fa23 = g, b; fb = angles) against the lane's pixel pair, 26 vector
+// instructions for the similarity, then one per channel for the messages of the position before (walk_messages):
+// acc[k] += sim * q[k] on (pixel 0, pixel 1) pairs.  The same operations on the same operands as the C++ form (step), so
+// the same bits; written out because the compiler's code for it carries two to four register moves per position (a packed
+// operand that needs the second register of a pair in both halves), keeps the six exponentials back to back and fills the
+// waits between dependent instructions with s_nop.  Here a component is selected by op_sel, the exponentials sit between
+// the packed operations of the other kernels, no instruction reads a register that the instruction in front of it wrote
+// (gfx950 wants one wait state between a packed or transcendental write and its use), and a position's last additions
+// and its message updates run inside the next position, where they wait for nothing.  The state that crosses positions:
+// s12 = 2^-x1 + 2^-x2 and s3 = 2^-x3 of the position just evaluated (pinned to two register pairs so that their halves
+// have names), and that position's channel vector, which the caller keeps.  sim_prev receives the finished similarity of
+// the position before.  LOW: the fourteen fixed registers are v[154:167] instead of v[242:255], for kernels built for
+// three blocks per CU (168 registers per lane).
+// wx, wy, wz: -log2 of the three weights for (pixel 0, pixel 1), +inf where the position is the pixel itself or the pixel
+// has no neighbour there.
+#define FS_SUBQ(d, a, b, sel) "v_pk_add_f32 " d ", " a ", " b " " sel " neg_lo:[0,1] neg_hi:[0,1]\n"
+#define FS_LO "op_sel_hi:[0,1]"
+#define FS_HI "op_sel:[1,0]"
+#if FS_ASM_ABL == 1
+#define FS_EXP(r) ""
+#elif FS_ASM_ABL == 3
+#define FS_EXP(r) "v_mov_b32_e32 " r ", " r "\n"
+#elif FS_ASM_ABL == 4
+#define FS_EXP(r) "v_mul_f32_e32 " r ", " r ", " r "\n"
+#else
+#define FS_EXP(r) "v_exp_f32_e64 " r ", -" r "\n"
+#endif
+// P0 .. P6: the seven register pairs; P1L/P1H, P3L/P3H, P6L/P6H: the halves of three of them
+#define FS_WALK_SIM_TEXT(P0, P1, P2, P3, P4, P5, P6, P1L, P1H, P3L, P3H, P6L, P6H)                                      \
+    "v_pk_add_f32 %[svp], " P6 ", " P3 "\n"                            /* the position before, finished   */           \
+    FS_SUBQ(P0, "%[fa01]", "%[cd]", FS_LO)                             /* e  = depth difference           */           \
+    FS_SUBQ(P1, "%[fa01]", "%[cr]", FS_HI)                             /* e0 = red                        */           \
+    "v_pk_fma_f32 " P2 ", " P0 ", %[pC], %[pB]\n"                                                                       \
+    FS_SUBQ(P3, "%[fa23]", "%[cg]", FS_LO)                             /* e1 = green                      */           \
+    "v_pk_mul_f32 " P4 ", " P0 ", " P0 "\n"                                                                             \
+    "v_pk_fma_f32 " P2 ", " P0 ", " P2 ", 1.0 op_sel_hi:[1,1,0]\n"                                                      \
+    "v_pk_fma_f32 " P1 ", " P1 ", " P1 ", %[wy]\n"                                                                      \
+    "v_pk_mul_f32 " P4 ", " P4 ", " P2 "\n"                            /* u / a^2                         */           \
+    FS_SUBQ(P5, "%[fa23]", "%[cb]", FS_HI)                             /* e2 = blue                       */           \
+    "v_pk_fma_f32 " P6 ", %[K1], " P4 ", %[wx]\n"                      /* x1                              */           \
+    "v_pk_fma_f32 " P1 ", " P3 ", " P3 ", " P1 "\n"                                                                     \
+    FS_EXP(P6L)                                                                                                         \
+    FS_SUBQ(P3, "%[fb]", "%[ca0]", FS_LO)                              /* g0                              */           \
+    FS_EXP(P6H)                                                                                                         \
+    "v_pk_fma_f32 " P1 ", " P5 ", " P5 ", " P1 "\n"                                                                     \
+    FS_SUBQ(P5, "%[fb]", "%[ca1]", FS_HI)                              /* g1                              */           \
+    "v_pk_fma_f32 " P1 ", %[K2], " P4 ", " P1 "\n"                     /* x2                              */           \
+    "v_pk_fma_f32 " P3 ", " P3 ", " P3 ", %[wz]\n"                                                                      \
+    FS_EXP(P1L)                                                                                                         \
+    "v_pk_fma_f32 " P3 ", " P5 ", " P5 ", " P3 "\n"                                                                     \
+    FS_EXP(P1H)                                                                                                         \
+    "v_pk_fma_f32 " P3 ", %[K3], " P4 ", " P3 "\n"                     /* x3                              */           \
+    "v_pk_add_f32 " P6 ", " P6 ", " P1 "\n"                                                                             \
+    FS_EXP(P3L)                                                                                                         \
+    FS_EXP(P3H)
+#define FS_WALK_SIM_IN                                                                                                   \
+    [fa01] "v"(fa01), [fa23] "v"(fa23), [fb] "v"(fb), [cd] "v"(cd), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [ca0] "v"(ca0),  \
+        [ca1] "v"(ca1), [pB] "v"(pB), [pC] "v"(pC), [K1] "v"(KA1), [K2] "v"(KA2), [K3] "v"(KA3), [wx] "s"(wx), [wy] "s"(wy),     \
+        [wz] "s"(wz)
+template <bool LOW = false>
+__device__ __forceinline__ void walk_similarity(f2 &sim_prev, f2 &s12, f2 &s3, f2 fa01, f2 fa23, f2 fb, f2 cd, f2 cr, f2 cg, f2 cb, f2 ca0,
+                                                f2 ca1, f2 pB, f2 pC, f2 KA1, f2 KA2, f2 KA3, f2 wx, f2 wy, f2 wz)
+{
+    if (LOW)
+        asm volatile(FS_WALK_SIM_TEXT("v[154:155]", "v[156:157]", "v[158:159]", "v[160:161]", "v[162:163]", "v[164:165]", "v[166:167]",
+                                      "v156", "v157", "v160", "v161", "v166", "v167")
+                     : [svp] "=&v"(sim_prev), "+{v[166:167]}"(s12), "+{v[160:161]}"(s3)
+                     : FS_WALK_SIM_IN
+                     : "v154", "v155", "v156", "v157", "v158", "v159", "v162", "v163", "v164", "v165");
+    else
+        asm volatile(FS_WALK_SIM_TEXT("v[242:243]", "v[244:245]", "v[246:247]", "v[248:249]", "v[250:251]", "v[252:253]", "v[254:255]",
+                                      "v244", "v245", "v248", "v249", "v254", "v255")
+                     : [svp] "=&v"(sim_prev), "+{v[254:255]}"(s12), "+{v[248:249]}"(s3)
+                     : FS_WALK_SIM_IN
+                     : "v242", "v243", "v244", "v245", "v246", "v247", "v250", "v251", "v252", "v253");
+}
+#undef FS_WALK_SIM_TEXT
+#undef FS_WALK_SIM_IN
+#undef FS_SUBQ
+#undef FS_LO
+#undef FS_HI
+#undef FS_EXP
+// acc[k] += sim * q[k], k = 0 .. 3, for both pixels of the pair: one quad of channels (q01 = channels 0, 1; q23 = 2, 3), the
+// channel taken from its register pair by op_sel
+__device__ __forceinline__ void walk_messages_quad(f2 &a0, f2 &a1, f2 &a2, f2 &a3, f2 sim, f2 q01, f2 q23)
+{
+    if (FS_ASM_ABL == 2) return;
+    asm volatile("v_pk_fma_f32 %[a0], %[sv], %[q01], %[a0] op_sel_hi:[1,0,1]\n"
+                 "v_pk_fma_f32 %[a1], %[sv], %[q01], %[a1] op_sel:[0,1,0]\n"
+                 "v_pk_fma_f32 %[a2], %[sv], %[q23], %[a2] op_sel_hi:[1,0,1]\n"
+                 "v_pk_fma_f32 %[a3], %[sv], %[q23], %[a3] op_sel:[0,1,0]\n"
+                 : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3)
+                 : [sv] "v"(sim), [q01] "v"(q01), [q23] "v"(q23));
+}
+#endif
+   // s_src entry of a channel that reads zeros
 
 // per-tile record of crf_tile_active_kernel (TILE_REC ints): [0] = count A of listed labels,
 // [REC_MASK .. REC_MASK+MASK_WORDS) = bit mask, [REC_LAB .. REC_LAB+A) = the labels, ascending

@@ -33,93 +33,6 @@ namespace {
 // (get_unary_potentials_and_initial_probabilities, find_surfaces.py:456-477).
 // ---------------------------------------------------------------------------
 
-#if FS_ASM_STEP
-// One window position of the shared rows in the instruction order it should issue in (Gaussian similarity, weights folded
-// into the exponents, depth series): the neighbour's record (fa01 = depth, r; fa23 = g, b; fb = angles) against the lane's
-// pixel pair, 26 vector instructions for the similarity, then one per channel for the messages of the position before
-// (walk_messages): ap[k] += sim * q[k] on (pixel 0, pixel 1) pairs.  The same operations on the same operands as the C++
-// form in fused_accumulate (step), so the same bits; written out because the compiler's code for it carries two to four
-// register moves per position (a packed operand that needs the second register of a pair in both halves), keeps the six
-// exponentials back to back and fills the waits between dependent instructions with s_nop.  Here a component is selected
-// by op_sel, the exponentials sit between the packed operations of the other kernels, no instruction reads a register
-// that the instruction in front of it wrote (gfx950 wants one wait state between a packed or transcendental write and
-// its use), and a position's last additions and its message updates run inside the next position, where they wait for
-// nothing.  The state that crosses positions: s12 = 2^-x1 + 2^-x2 and s3 = 2^-x3 of the position just evaluated (pinned
-// to v[254:255] and v[248:249] so that their halves have names), and that position's channel vector, which the caller
-// keeps.  sim_prev receives the finished similarity of the position before.  Temporaries are v[242:247], v[250:253].
-// wx, wy, wz: -log2 of the three weights for (pixel 0, pixel 1), +inf where the position is the pixel itself.
-#define FS_SUBQ(d, a, b, sel) "v_pk_add_f32 " d ", " a ", " b " " sel " neg_lo:[0,1] neg_hi:[0,1]\n"
-#define FS_LO "op_sel_hi:[0,1]"
-#if FS_ASM_ABL == 1
-#define FS_EXP(r) ""
-#elif FS_ASM_ABL == 3
-#define FS_EXP(r) "v_mov_b32_e32 " r ", " r "\n"
-#elif FS_ASM_ABL == 4
-#define FS_EXP(r) "v_mul_f32_e32 " r ", " r ", " r "\n"
-#else
-#define FS_EXP(r) "v_exp_f32_e64 " r ", -" r "\n"
-#endif
-#define FS_HI "op_sel:[1,0]"
-__device__ __forceinline__ void walk_similarity(f2 &sim_prev, f2 &s12, f2 &s3, f2 fa01, f2 fa23, f2 fb, f2 cd, f2 cr, f2 cg, f2 cb, f2 ca0,
-                                                f2 ca1, f2 pB, f2 pC, f2 KA1, f2 KA2, f2 KA3, f2 wx, f2 wy, f2 wz)
-{
-    asm volatile("v_pk_add_f32 %[svp], v[254:255], v[248:249]\n"                        /* the position before, finished   */
-                 FS_SUBQ("v[242:243]", "%[fa01]", "%[cd]", FS_LO)                       /* e  = depth difference           */
-                 FS_SUBQ("v[244:245]", "%[fa01]", "%[cr]", FS_HI)                       /* e0 = red                        */
-                 "v_pk_fma_f32 v[246:247], v[242:243], %[pC], %[pB]\n"
-                 FS_SUBQ("v[248:249]", "%[fa23]", "%[cg]", FS_LO)                       /* e1 = green                      */
-                 "v_pk_mul_f32 v[250:251], v[242:243], v[242:243]\n"
-                 "v_pk_fma_f32 v[246:247], v[242:243], v[246:247], 1.0 op_sel_hi:[1,1,0]\n"
-                 "v_pk_fma_f32 v[244:245], v[244:245], v[244:245], %[wy]\n"
-                 "v_pk_mul_f32 v[250:251], v[250:251], v[246:247]\n"                    /* u / a^2                         */
-                 FS_SUBQ("v[252:253]", "%[fa23]", "%[cb]", FS_HI)                       /* e2 = blue                       */
-                 "v_pk_fma_f32 v[254:255], %[K1], v[250:251], %[wx]\n"                  /* x1                              */
-                 "v_pk_fma_f32 v[244:245], v[248:249], v[248:249], v[244:245]\n"
-                 FS_EXP("v254")
-                 FS_SUBQ("v[248:249]", "%[fb]", "%[ca0]", FS_LO)                        /* g0                              */
-                 FS_EXP("v255")
-                 "v_pk_fma_f32 v[244:245], v[252:253], v[252:253], v[244:245]\n"
-                 FS_SUBQ("v[252:253]", "%[fb]", "%[ca1]", FS_HI)                        /* g1                              */
-                 "v_pk_fma_f32 v[244:245], %[K2], v[250:251], v[244:245]\n"             /* x2                              */
-                 "v_pk_fma_f32 v[248:249], v[248:249], v[248:249], %[wz]\n"
-                 FS_EXP("v244")
-                 "v_pk_fma_f32 v[248:249], v[252:253], v[252:253], v[248:249]\n"
-                 FS_EXP("v245")
-                 "v_pk_fma_f32 v[248:249], %[K3], v[250:251], v[248:249]\n"             /* x3                              */
-                 "v_pk_add_f32 v[254:255], v[254:255], v[244:245]\n"
-                 FS_EXP("v248")
-                 FS_EXP("v249")
-                 : [svp] "=&v"(sim_prev), "+{v[254:255]}"(s12), "+{v[248:249]}"(s3)
-                 : [fa01] "v"(fa01), [fa23] "v"(fa23), [fb] "v"(fb), [cd] "v"(cd), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb),
-                   [ca0] "v"(ca0), [ca1] "v"(ca1), [pB] "v"(pB), [pC] "v"(pC), [K1] "v"(KA1), [K2] "v"(KA2), [K3] "v"(KA3),
-                   [wx] "s"(wx), [wy] "s"(wy), [wz] "s"(wz)
-                 : "v242", "v243", "v244", "v245", "v246", "v247", "v250", "v251", "v252", "v253");
-}
-#undef FS_SUBQ
-#undef FS_LO
-#undef FS_HI
-#undef FS_EXP
-// ap[k] += sim * q[k] for both pixels of the pair, the channel taken from its register pair by op_sel
-template <int NQ>
-__device__ __forceinline__ void walk_messages(f2 (&ap)[8], f2 sim, f2 q00, f2 q01, f2 q10, f2 q11)
-{
-    if (FS_ASM_ABL == 2) return;
-    asm volatile("v_pk_fma_f32 %[a0], %[sv], %[q00], %[a0] op_sel_hi:[1,0,1]\n"
-                 "v_pk_fma_f32 %[a1], %[sv], %[q00], %[a1] op_sel:[0,1,0]\n"
-                 "v_pk_fma_f32 %[a2], %[sv], %[q01], %[a2] op_sel_hi:[1,0,1]\n"
-                 "v_pk_fma_f32 %[a3], %[sv], %[q01], %[a3] op_sel:[0,1,0]\n"
-                 : [a0] "+v"(ap[0]), [a1] "+v"(ap[1]), [a2] "+v"(ap[2]), [a3] "+v"(ap[3])
-                 : [sv] "v"(sim), [q00] "v"(q00), [q01] "v"(q01));
-    if (NQ > 1)
-        asm volatile("v_pk_fma_f32 %[a4], %[sv], %[q10], %[a4] op_sel_hi:[1,0,1]\n"
-                     "v_pk_fma_f32 %[a5], %[sv], %[q10], %[a5] op_sel:[0,1,0]\n"
-                     "v_pk_fma_f32 %[a6], %[sv], %[q11], %[a6] op_sel_hi:[1,0,1]\n"
-                     "v_pk_fma_f32 %[a7], %[sv], %[q11], %[a7] op_sel:[0,1,0]\n"
-                     : [a4] "+v"(ap[4]), [a5] "+v"(ap[5]), [a6] "+v"(ap[6]), [a7] "+v"(ap[7])
-                     : [sv] "v"(sim), [q10] "v"(q10), [q11] "v"(q11));
-}
-#endif
-
 // Messages of one lane's two vertically adjacent pixels (LDS rows trow, trow+1 of the tile, column col)
 // from the staged chunk: acc[i][k] += sum over the window of sim(pixel i, neighbour) * Q_neighbour[k].
 // Both rows are carried as packed pairs, one v_pk_* instruction per operation.  The 2r region rows that
@@ -260,7 +173,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
     Row cur = row_of(1);
     Operands nxt = read(cur, 0);
 #if FS_ASM_STEP
-    // Experiment build: the shared rows in assembly (walk_similarity).  A position's similarity is finished, and its messages
+    // The shared rows in assembly (walk_similarity, k_crf_common.h).  A position's similarity is finished, and its messages
     // are added, while the next position is evaluated; nothing is pending before the first position (zeros).  The records
     // are read as register pairs, which is the form the assembly's operands take.
     constexpr bool ASM_WALK = MODE == 0 && FOLD && FS_DEPTH_SERIES && !FS_SKIPSIM;
@@ -300,13 +213,16 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
                 f2 sim_prev;
                 walk_similarity(sim_prev, s12, s3, o.fa01, o.fa23, o.fb, cd, cr, cg, cb, ca0, ca1, pB, pC, KA1, KA2, KA3,
                                 f2{w0.x, w1.x}, f2{w0.y, w1.y}, f2{w0.z, w1.z});
-                walk_messages<NQ>(ap, sim_prev, qp00, qp01, qp10, qp11);
+                walk_messages_quad(ap[0], ap[1], ap[2], ap[3], sim_prev, qp00, qp01);
+                if (NQ > 1) walk_messages_quad(ap[4], ap[5], ap[6], ap[7], sim_prev, qp10, qp11);
                 qp00 = o.q00; qp01 = o.q01; qp10 = o.q10; qp11 = o.q11;
                 __builtin_amdgcn_sched_barrier(0);
             }
             cur = below;
         }
-        walk_messages<NQ>(ap, s12 + s3, qp00, qp01, qp10, qp11);     // the last shared position
+        const f2 sim_last = s12 + s3;                        // the last shared position
+        walk_messages_quad(ap[0], ap[1], ap[2], ap[3], sim_last, qp00, qp01);
+        if (NQ > 1) walk_messages_quad(ap[4], ap[5], ap[6], ap[7], sim_last, qp10, qp11);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             acc[0][k] = ap[k].x;

@@ -95,6 +95,16 @@ struct PairSim {
     }
 };
 
+// blocks per CU the kernel is compiled for: as many as rings (plus the 6 KB of tables a block keeps) fit the CU's 160 KB of
+// LDS, three at most (the kernel needs no more than the 168 registers that leaves a lane); a ring of NQP quad planes of Q
+// and the features takes 16 NQP + 24 bytes per pixel.  Run-time radius: sized for the largest one.
+template <int R, int NQP>
+constexpr int roll_blocks_per_cu()
+{
+    const int fit = 160 * 1024 / ((FTW + 2 * (R ? R : kMaxRadius)) * RING * (16 * NQP + 24) + 6 * 1024);
+    return R == 0 ? (fit >= 2 ? 2 : 1) : (fit >= 3 ? 3 : (fit >= 2 ? 2 : 1));
+}
+
 // One window row: the lane's pair against the 2r + 1 neighbours of ring row `slot`.  on0 / on1: whether pixel 0 /
 // pixel 1 has this row in its window; centre0 / centre1: whether it is the pixel's own row (its centre is excluded).
 // NQ: quads of channels read and accumulated; NQP: quad planes of the ring (the feature planes lie behind them).
@@ -141,6 +151,57 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[NQP * 4], const PairSim<MODE,
         }
         sim.template step<NQ>(acc, o, w0, w1);
     };
+#if FS_ASM_STEP
+    // Compile-time radius, trained constants: the row in assembly (walk_similarity, k_crf_common.h).  A position's
+    // similarity is finished, and its messages are added, while the next position is evaluated; the row's last position is
+    // finished behind the loop.  The records are read as register pairs, the form the assembly's operands take.
+    // (not the 16-channels-per-walk kernel at r = 7: with its accumulators and the fixed registers it spills, 260 against 255 us
+    // per update of the dense 1280x960 frames)
+    if (R > 0 && !(R == 7 && NQP >= 4) && UNIFORM && MODE == 0 && FS_DEPTH_SERIES) {
+        constexpr bool LOW = roll_blocks_per_cu<R, NQP>() == 3;      // 168 registers per lane: the low set of fixed registers
+        struct Pairs { f2 fa01, fa23, fb, q[2 * NQ]; };
+        auto read_pairs = [&](int k) {
+            Pairs o;
+            const f2 *a2 = reinterpret_cast<const f2 *>(A + k);
+            o.fa01 = a2[0]; o.fa23 = a2[1];
+            o.fb = *reinterpret_cast<const f2 *>(B + k);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const f2 *q2 = reinterpret_cast<const f2 *>(lds4 + iQ[j] + k);
+                o.q[2 * j] = q2[0]; o.q[2 * j + 1] = q2[1];
+            }
+            return o;
+        };
+        f2 s12 = f2{0.f, 0.f}, s3 = s12;
+        Pairs np = read_pairs(0), prev = np;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            const Pairs o = np;
+            if (k < 2 * R) np = read_pairs(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float4 w0 = row0, w1 = row1;
+            if (k == R) {
+                if (centre0) w0 = uoff;
+                if (centre1) w1 = uoff;
+            }
+            f2 sim_prev;
+            walk_similarity<LOW>(sim_prev, s12, s3, o.fa01, o.fa23, o.fb, sim.cd, sim.cr, sim.cg, sim.cb, sim.ca0, sim.ca1, sim.pB, sim.pC,
+                                 sim.KA1, sim.KA2, sim.KA3, f2{w0.x, w1.x}, f2{w0.y, w1.y}, f2{w0.z, w1.z});
+            if (k > 0) {
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+                    walk_messages_quad(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3], sim_prev, prev.q[2 * j], prev.q[2 * j + 1]);
+            }
+            prev = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const f2 sim_last = s12 + s3;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            walk_messages_quad(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3], sim_last, prev.q[2 * j], prev.q[2 * j + 1]);
+        return;
+    }
+#endif
     RollOperands<NQ> nxt = read(0);
     if (R > 0) {
 #pragma unroll
@@ -161,16 +222,6 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[NQP * 4], const PairSim<MODE,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// blocks per CU the kernel is compiled for: as many as rings (plus the 6 KB of tables a block keeps) fit the CU's 160 KB of
-// LDS, three at most (the kernel needs no more than the 168 registers that leaves a lane); a ring of NQP quad planes of Q
-// and the features takes 16 NQP + 24 bytes per pixel.  Run-time radius: sized for the largest one.
-template <int R, int NQP>
-constexpr int roll_blocks_per_cu()
-{
-    const int fit = 160 * 1024 / ((FTW + 2 * (R ? R : kMaxRadius)) * RING * (16 * NQP + 24) + 6 * 1024);
-    return R == 0 ? (fit >= 2 ? 2 : 1) : (fit >= 3 ? 3 : (fit >= 2 ? 2 : 1));
 }
 
 // WIDE: one pass of an update whose tiles carry more channels than a lane's registers hold (NCH * 8).  The pass works on
