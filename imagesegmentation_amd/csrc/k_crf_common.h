@@ -127,8 +127,9 @@ constexpr unsigned kNoPlane = 0xffffffffu;
 // and its message updates run inside the next position, where they wait for nothing.  The state that crosses positions:
 // s12 = 2^-x1 + 2^-x2 and s3 = 2^-x3 of the position just evaluated (pinned to two register pairs so that their halves
 // have names), and that position's channel vector, which the caller keeps.  sim_prev receives the finished similarity of
-// the position before.  LOW: the fourteen fixed registers are v[154:167] instead of v[242:255], for kernels built for
-// three blocks per CU (168 registers per lane).
+// the position before.  The fourteen fixed registers are v[242:255]: for kernels built for at most two blocks per CU
+// (a kernel built for three has 168 registers per lane; the rolling kernel at r = 10 was tried with v[154:167] and spilled
+// 21 registers for 1 % of time, so it keeps the compiler's code).
 // wx, wy, wz: -log2 of the three weights for (pixel 0, pixel 1), +inf where the position is the pixel itself or the pixel
 // has no neighbour there.
 #define FS_SUBQ(d, a, b, sel) "v_pk_add_f32 " d ", " a ", " b " " sel " neg_lo:[0,1] neg_hi:[0,1]\n"
@@ -175,22 +176,14 @@ constexpr unsigned kNoPlane = 0xffffffffu;
     [fa01] "v"(fa01), [fa23] "v"(fa23), [fb] "v"(fb), [cd] "v"(cd), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [ca0] "v"(ca0),  \
         [ca1] "v"(ca1), [pB] "v"(pB), [pC] "v"(pC), [K1] "v"(KA1), [K2] "v"(KA2), [K3] "v"(KA3), [wx] "s"(wx), [wy] "s"(wy),     \
         [wz] "s"(wz)
-template <bool LOW = false>
 __device__ __forceinline__ void walk_similarity(f2 &sim_prev, f2 &s12, f2 &s3, f2 fa01, f2 fa23, f2 fb, f2 cd, f2 cr, f2 cg, f2 cb, f2 ca0,
                                                 f2 ca1, f2 pB, f2 pC, f2 KA1, f2 KA2, f2 KA3, f2 wx, f2 wy, f2 wz)
 {
-    if (LOW)
-        asm volatile(FS_WALK_SIM_TEXT("v[154:155]", "v[156:157]", "v[158:159]", "v[160:161]", "v[162:163]", "v[164:165]", "v[166:167]",
-                                      "v156", "v157", "v160", "v161", "v166", "v167")
-                     : [svp] "=&v"(sim_prev), "+{v[166:167]}"(s12), "+{v[160:161]}"(s3)
-                     : FS_WALK_SIM_IN
-                     : "v154", "v155", "v156", "v157", "v158", "v159", "v162", "v163", "v164", "v165");
-    else
-        asm volatile(FS_WALK_SIM_TEXT("v[242:243]", "v[244:245]", "v[246:247]", "v[248:249]", "v[250:251]", "v[252:253]", "v[254:255]",
-                                      "v244", "v245", "v248", "v249", "v254", "v255")
-                     : [svp] "=&v"(sim_prev), "+{v[254:255]}"(s12), "+{v[248:249]}"(s3)
-                     : FS_WALK_SIM_IN
-                     : "v242", "v243", "v244", "v245", "v246", "v247", "v250", "v251", "v252", "v253");
+    asm volatile(FS_WALK_SIM_TEXT("v[242:243]", "v[244:245]", "v[246:247]", "v[248:249]", "v[250:251]", "v[252:253]", "v[254:255]",
+                                  "v244", "v245", "v248", "v249", "v254", "v255")
+                 : [svp] "=&v"(sim_prev), "+{v[254:255]}"(s12), "+{v[248:249]}"(s3)
+                 : FS_WALK_SIM_IN
+                 : "v242", "v243", "v244", "v245", "v246", "v247", "v250", "v251", "v252", "v253");
 }
 #undef FS_WALK_SIM_TEXT
 #undef FS_WALK_SIM_IN

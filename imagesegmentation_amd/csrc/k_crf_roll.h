@@ -156,9 +156,9 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[NQP * 4], const PairSim<MODE,
     // similarity is finished, and its messages are added, while the next position is evaluated; the row's last position is
     // finished behind the loop.  The records are read as register pairs, the form the assembly's operands take.
     // (not the 16-channels-per-walk kernel at r = 7: with its accumulators and the fixed registers it spills, 260 against 255 us
-    // per update of the dense 1280x960 frames)
-    if (R > 0 && !(R == 7 && NQP >= 4) && UNIFORM && MODE == 0 && FS_DEPTH_SERIES) {
-        constexpr bool LOW = roll_blocks_per_cu<R, NQP>() == 3;      // 168 registers per lane: the low set of fixed registers
+    // per update of the dense 1280x960 frames; not the kernels built for three blocks per CU, whose 168 registers end below
+    // the fixed ones)
+    if (R > 0 && !(R == 7 && NQP >= 4) && roll_blocks_per_cu<R, NQP>() < 3 && UNIFORM && MODE == 0 && FS_DEPTH_SERIES) {
         struct Pairs { f2 fa01, fa23, fb, q[2 * NQ]; };
         auto read_pairs = [&](int k) {
             Pairs o;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void roll_row(f2 (&acc)[NQP * 4], const PairSim<MODE,
                 if (centre1) w1 = uoff;
             }
             f2 sim_prev;
-            walk_similarity<LOW>(sim_prev, s12, s3, o.fa01, o.fa23, o.fb, sim.cd, sim.cr, sim.cg, sim.cb, sim.ca0, sim.ca1, sim.pB, sim.pC,
+            walk_similarity(sim_prev, s12, s3, o.fa01, o.fa23, o.fb, sim.cd, sim.cr, sim.cg, sim.cb, sim.ca0, sim.ca1, sim.pB, sim.pC,
                                  sim.KA1, sim.KA2, sim.KA3, f2{w0.x, w1.x}, f2{w0.y, w1.y}, f2{w0.z, w1.z});
             if (k > 0) {
 #pragma unroll

@@ -2,7 +2,7 @@
 # Kernel traces and counter passes of the round's workloads.  Usage (on the GPU box):
 #   tools/profile_round.sh gpurun_out/prof_r3 [traces|pmc|all]
 # Writes per workload <out>/<name>/ (rocprofv3 --kernel-trace --stats of `python bench.py ...` with the bench line of the
-# same run), and per CRF workload the FETCH_SIZE / WRITE_SIZE / SQ / GRBM passes (counters never share a run with a
+# same run; ONLY="name ..." in the environment restricts the run to those workloads), and per CRF workload the FETCH_SIZE / WRITE_SIZE / SQ / GRBM passes (counters never share a run with a
 # trace; one --pmc pass per run).  tools/collect_profiles.py copies the summaries into profiles/.
 out=$1
 what=${2:-all}
@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 trace() {   # name, bench args...
   local name=$1; shift
+  [[ -n "$ONLY" && " $ONLY " != *" $name "* ]] && return
   mkdir -p "$out/$name"
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name/stats" -- python bench.py "$@" --no-cpu-baseline --no-stats-leg \
       > "$out/$name/bench_under_rocprof.json" 2> "$out/$name/stats.log" || { echo "$name: stats run failed"; tail -5 "$out/$name/stats.log"; exit 1; }
@@ -26,6 +27,7 @@ pmc() {     # name, counters, bench args...
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU"
 passes() {  # prefix, bench args...: the four counter passes of one workload
   local pre=$1; shift
+  [[ -n "$ONLY" && " $ONLY " != *" $pre "* ]] && return
   pmc ${pre}_fetch FETCH_SIZE "$@"
   pmc ${pre}_write WRITE_SIZE "$@"
   pmc ${pre}_sq1 "$SQ" "$@"
