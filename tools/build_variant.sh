@@ -7,6 +7,6 @@ name=$1; shift
 cd "$(dirname "$0")/../imagesegmentation_amd/csrc"
 make -j8 > /dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math "$@" -c k_crf_fused_r7.hip -o /tmp/k_crf_fused_r7_$name.o
-objs=$(ls *.o | grep -v k_crf_fused_r7.o)
+objs=$(ls *.o | grep -v cwalk | grep -v k_crf_fused_r7.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfs_hip_$name.so $objs /tmp/k_crf_fused_r7_$name.o
 echo ../libfs_hip_$name.so

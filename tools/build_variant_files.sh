@@ -14,6 +14,6 @@ for f in $files; do
   objs="$objs $o"; skip="$skip ${f%.hip}.o"
 done
 wait
-rest=$(ls *.o | grep -v -x -F "$(echo $skip | tr ' ' '\n')")
+rest=$(ls *.o | grep -v cwalk | grep -v -x -F "$(echo $skip | tr ' ' '\n')")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfs_hip_$name.so $rest $objs
 echo ../libfs_hip_$name.so
