@@ -10,8 +10,10 @@
 // walk of the fused update, FS_SKIPSIM=1 only the similarity's arithmetic inside it, FS_SKIPQ=1 the staging of Q,
 // FS_SKIPFIN=1 the epilogue; FS_DEPTH_SERIES=0 evaluates the relative depth difference with a reciprocal per neighbour
 // instead of the series (see fused_accumulate); FS_CRF_MAX_BLOCKS=256u launches one block per CU;
-// FS_ASM_STEP=1 walks the shared rows with the hand-scheduled assembly of walk_similarity (same bits, same time as the
-// compiler's code: profiles/r3_walk_instruction_costs.txt), FS_ASM_ABL its ablations.
+// FS_ASM_STEP=0 leaves the window walks to the compiler instead of the hand-scheduled assembly of walk_similarity (same
+// bits, about 2 % slower at r = 7 and 5 % at r = 15; the Makefile builds libfs_hip_cwalk.so that way for the test that
+// compares the two), FS_ASM_ABL=1..4 are ablations of the assembly (wrong results, for pricing its instructions);
+// FS_TILE_CLOCKS=1 adds cycle counters to the phases of the r = 7 kernel's tiles (tools/phase_clocks.py).
 #ifndef FS_CRF_MAX_BLOCKS
 #define FS_CRF_MAX_BLOCKS 512u      // resident blocks of the r = 7 kernel: two per CU (256u: one per CU, one wave per SIMD)
 #endif
@@ -34,7 +36,7 @@
 #define FS_TILE_CLOCKS 0             // 1: per-phase cycle counts of the r = 7 kernel's tiles (fs_debug_phase_clocks)
 #endif
 #ifndef FS_ASM_STEP
-#define FS_ASM_STEP 1               // the shared rows of the r = 7 window walk in assembly (walk_similarity); 0: the compiler's code for step()
+#define FS_ASM_STEP 1               // window walks in assembly (walk_similarity); 0: the compiler's code for step()
 #endif
 #ifndef FS_ASM_ABL
 #define FS_ASM_ABL 0                // with FS_ASM_STEP: 1 no exponentials, 2 no messages, 3 / 4 a v_mov / v_mul in place of each exponential
