@@ -303,8 +303,13 @@ def main():
         else:
             hdt = hdt_own
         per_frame_bytes = H * W * (2 + 3) + H * W * (8 + 12 + 12 + 8 + 4 + 8)
+        # what crosses the link: a call of more than 16 frames sends patches and surfaces as 16-bit and edges as 8-bit images
+        # and widens them on the host (FS_NO_NARROW_DOWNLOADS=1: as they are)
+        narrow = n > 16 and os.environ.get("FS_NO_NARROW_DOWNLOADS", "0")[:1] != "1" and (H * W) % 4 == 0
+        link_bytes = H * W * (2 + 3) + H * W * (8 + 12 + 12 + (2 + 1 + 2 if narrow else 8 + 4 + 8))
         host_leg = {"value": world * n * hs / hdt, "unit": "images/s", "steps": hs, "ms_per_step": 1e3 * hdt / hs,
-                    "bytes_per_frame": per_frame_bytes, "pcie_gbs": hs * world * n * per_frame_bytes / hdt / 1e9,
+                    "bytes_per_frame": per_frame_bytes, "bytes_per_frame_over_pcie": link_bytes,
+                    "pcie_gbs": hs * world * n * link_bytes / hdt / 1e9,
                     "per_rank_images_per_s": per_rank,
                     "note": "page-locked host arrays in, six page-locked output arrays back; measured after the headline loop on "
                             "all ranks at once (whole-job rate = frames of all ranks / the slowest rank's time; per_rank = each "

@@ -5,7 +5,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 
 #include "../../include/fs_hip.h"
 #include "fs_common.h"
@@ -65,6 +68,14 @@ struct fs_ctx {
     hipEvent_t early_events[2] = {nullptr, nullptr};   // host-buffer calls of one chunk: outputs leave as they are completed
     bool early_downloads = true;                   // FS_NO_EARLY_DOWNLOADS=1 switches that off (measurements)
     HostBuf publish_host;                          // the word
+    // Host-buffer calls of several chunks send the label images as 16-bit patches and surfaces and 8-bit edges (narrow_dev,
+    // copies of a chunk's int64 / int32 images) to page-locked staging (narrow_host) and widen them into the caller's
+    // arrays on worker threads: 1.5 instead of 6.2 MB of a frame's 15.8 cross the link, which bounds that entry point.
+    bool narrow_downloads = true;                  // FS_NO_NARROW_DOWNLOADS=1 switches that off (measurements)
+    int widen_threads = 4;                         // FS_WIDEN_THREADS
+    DevBuf narrow_dev;
+    HostBuf narrow_host;
+    std::vector<hipEvent_t> narrow_events;         // per chunk: its narrow images have arrived
     HostBuf frames_in_host;                        // frames of a small host-buffer call that arrive in pageable memory
     HostBuf stats_in_host;                         // ... and its inputs that arrive in pageable memory, on their way up
     HostBuf stats_small_host;                      // per-frame statistics: the small outputs on their way to the caller's arrays
@@ -456,6 +467,64 @@ constexpr int kCrfGroupPlanes = 37;            // ... when the similarity planes
 constexpr size_t kCrfGroupBytes = (size_t)24 << 30;  // ... and most bytes of one Q buffer of a group (there are two)
 constexpr int kPipeChunk = 16;  // frames per upload / compute / download step of the host-buffer entry point
 
+// ---- narrow copies of the label images for the host-buffer entry point ---------------------------------------------
+// patch labels and final labels lie in [0, kMaxLabels), depth edges are 0 or 1: 16 and 8 bits hold them
+__global__ __launch_bounds__(256) void narrow_patches_edges_kernel(const int32_t *__restrict__ patches, const int32_t *__restrict__ edges,
+                                                                   int16_t *__restrict__ p16, uint8_t *__restrict__ e8, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    if (p16) {
+        const int4 v = reinterpret_cast<const int4 *>(patches)[i];
+        reinterpret_cast<short4 *>(p16)[i] = make_short4((short)v.x, (short)v.y, (short)v.z, (short)v.w);
+    }
+    if (e8) {
+        const int4 v = reinterpret_cast<const int4 *>(edges)[i];
+        reinterpret_cast<uchar4 *>(e8)[i] = make_uchar4((unsigned char)v.x, (unsigned char)v.y, (unsigned char)v.z, (unsigned char)v.w);
+    }
+}
+__global__ __launch_bounds__(256) void narrow_surfaces_kernel(const int64_t *__restrict__ surfaces, int16_t *__restrict__ s16, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const longlong2 a = reinterpret_cast<const longlong2 *>(surfaces)[2 * i], b = reinterpret_cast<const longlong2 *>(surfaces)[2 * i + 1];
+    reinterpret_cast<short4 *>(s16)[i] = make_short4((short)a.x, (short)a.y, (short)b.x, (short)b.y);
+}
+// host side: back to the caller's int64 / int32 arrays (plain loops; the compiler vectorises the sign extension)
+void widen_i16_to_i64(const int16_t *src, int64_t *dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+void widen_u8_to_i32(const uint8_t *src, int32_t *dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+// The worker threads of one host-buffer call: chunk k's narrow images may be widened once the main thread has recorded the
+// event behind their copies (`posted` counts the chunks for which it has) and that event has completed.  Every chunk is cut
+// into `parts` jobs so that all workers share a chunk; a job is claimed through `next`.
+struct WidenJobs {
+    std::mutex m;
+    std::condition_variable cv;
+    int posted = 0;
+    bool abort = false;
+    std::atomic<int> next{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> workers;
+    // waits for the workers; `ok` false: they give up whatever has not been posted
+    void finish(bool ok)
+    {
+        if (workers.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!ok) abort = true;
+        }
+        cv.notify_all();
+        for (std::thread &t : workers) t.join();
+        workers.clear();
+    }
+    ~WidenJobs() { finish(false); }            // (a call that leaves early)
+};
+
 // CRF of n frames resident on the device: similarity planes, initial probabilities from
 // `labels32`, `iterations` mean-field updates, argmax.  S[i] label channels and max_active[i]
 // listed labels per tile (host arrays).  Frames are processed in groups; inside a group all
@@ -744,6 +813,8 @@ int fs_create(fs_ctx **out, int device, int height, int width, int max_batch)
     if (const char *e = getenv("FS_CRF_PLANES")) ctx->use_planes = e[0] == '1';
     if (const char *e = getenv("FS_NO_SPECULATION")) ctx->speculate = e[0] != '1';
     if (const char *e = getenv("FS_NO_EARLY_DOWNLOADS")) ctx->early_downloads = e[0] != '1';
+    if (const char *e = getenv("FS_NO_NARROW_DOWNLOADS")) ctx->narrow_downloads = e[0] != '1';
+    if (const char *e = getenv("FS_WIDEN_THREADS")) ctx->widen_threads = std::max(1, std::min(64, atoi(e)));
     if (build_tables(ctx)) return bail(0);
     if (ensure_frame_buffers(ctx)) return bail(0);
     // this GPU's copy of the static work space of fs_connected_components_noalloc: looked up here, once per
@@ -763,7 +834,7 @@ void fs_destroy(fs_ctx *ctx)
                       &ctx->mask, &ctx->edges, &ctx->patches64, &ctx->patches32, &ctx->surfaces64, &ctx->cc_parent,
                       &ctx->cc_count, &ctx->cc_newid, &ctx->cc_blocksum, &ctx->counts, &ctx->crf_queue, &ctx->curv_todo, &ctx->tile_recs, &ctx->st_in, &ctx->st_work, &ctx->st_descs, &ctx->st_lin,
                       &ctx->st_scratch, &ctx->st_out, &ctx->st_pool, &ctx->simH, &ctx->qa, &ctx->qb,
-                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB, &ctx->msg, &ctx->tile_order};
+                      &ctx->pot, &ctx->unary, &ctx->f1, &ctx->f2, &ctx->f3, &ctx->rows, &ctx->descs, &ctx->featA, &ctx->featB, &ctx->msg, &ctx->tile_order, &ctx->narrow_dev};
     for (DevBuf *b : bufs) b->release();
     for (auto &v : ctx->ev)
         for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -780,6 +851,8 @@ void fs_destroy(fs_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->stats_up_events)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->narrow_events) (void)hipEventDestroy(e);
+    ctx->narrow_host.release();
     ctx->spec_descs_host.release();
     ctx->publish_host.release();
     ctx->stats_small_host.release();
@@ -1244,10 +1317,56 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         (void)hipStreamSynchronize(ctx->out_stream);
         return -1;
     };
-    if (upload(0)) return drained();
+    // Calls of several chunks: the label images cross the link narrow and are widened by worker threads (see narrow_dev)
+    const bool narrow = ctx->narrow_downloads && chunks > 1 && N % 4 == 0 && (patches || edges || surfaces);
+    int16_t *p16d = nullptr, *s16d = nullptr, *p16h = nullptr, *s16h = nullptr;
+    uint8_t *e8d = nullptr, *e8h = nullptr;
+    WidenJobs jobs;
+    std::vector<std::thread> &workers = jobs.workers;
+    const int parts = narrow ? ctx->widen_threads : 0;
+    if (narrow) {
+        const size_t total = (size_t)n * N;
+        FS_HIP(ctx->narrow_dev.ensure(total * 5));
+        FS_HIP(ctx->narrow_host.ensure(total * 5));
+        p16d = ctx->narrow_dev.as<int16_t>(); s16d = p16d + total; e8d = reinterpret_cast<uint8_t *>(s16d + total);
+        p16h = ctx->narrow_host.as<int16_t>(); s16h = p16h + total; e8h = reinterpret_cast<uint8_t *>(s16h + total);
+        while (ctx->narrow_events.size() < (size_t)chunks) {
+            hipEvent_t e;
+            FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->narrow_events.push_back(e);
+        }
+        const int device = ctx->device;
+        std::vector<hipEvent_t> *events = &ctx->narrow_events;
+        for (int t = 0; t < parts; ++t)
+            workers.emplace_back([&jobs, events, device, chunks, parts, C, n, N, p16h, s16h, e8h, patches, surfaces, edges]() {
+                if (hipSetDevice(device) != hipSuccess) jobs.failed = 1;
+                for (;;) {
+                    const int j = jobs.next.fetch_add(1);
+                    if (j >= chunks * parts) return;
+                    const int k = j / parts, part = j - k * parts;
+                    {
+                        std::unique_lock<std::mutex> lk(jobs.m);
+                        jobs.cv.wait(lk, [&] { return jobs.posted > k || jobs.abort; });
+                        if (jobs.abort) return;
+                    }
+                    if (hipEventSynchronize((*events)[k]) != hipSuccess) { jobs.failed = 1; continue; }
+                    const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0), px = cn * N;
+                    const size_t lo = f0 * N + px * part / parts, hi = f0 * N + px * (part + 1) / parts;
+                    if (patches) widen_i16_to_i64(p16h + lo, patches + lo, hi - lo);
+                    if (surfaces) widen_i16_to_i64(s16h + lo, surfaces + lo, hi - lo);
+                    if (edges) widen_u8_to_i32(e8h + lo, edges + lo, hi - lo);
+                }
+            });
+    }
+    auto finish_workers = [&](bool ok) { jobs.finish(ok); };
+    auto drained_all = [&]() {
+        finish_workers(false);
+        return drained();
+    };
+    if (upload(0)) return drained_all();
     for (int k = 0; k < chunks; ++k) {
         const size_t f0 = (size_t)k * C, cn = std::min<size_t>(C, n - f0);
-        if (k + 1 < chunks && upload(k + 1)) return drained();
+        if (k + 1 < chunks && upload(k + 1)) return drained_all();
         FS_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_events[2 * k], 0));
         const size_t px = cn * N, o = f0 * N;
         // Each group of a chunk's outputs starts its way to the host as soon as the kernels that complete it are
@@ -1256,7 +1375,27 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         // and with several chunks the link, which bounds the call, starts on a chunk a CRF's length earlier (111
         // frames: 35.9 -> 33.5 ms).
         StageHook hook;
+        auto narrow_patches_edges = [&]() -> int {      // on the compute stream, behind the components
+            if (!narrow || (!patches && !edges)) return 0;
+            const size_t n4 = px / 4;
+            hipLaunchKernelGGL(narrow_patches_edges_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->patches32.as<int32_t>(), ctx->edges.as<int32_t>() + o, patches ? p16d + o : nullptr,      // (patches32: the chunk's, from 0)
+                               edges ? e8d + o : nullptr, n4);
+            FS_HIP(hipGetLastError());
+            return 0;
+        };
+        auto download_patches_edges = [&]() -> int {    // on the download stream
+            if (narrow) {
+                if (patches) FS_HIP(hipMemcpyAsync(p16h + o, p16d + o, px * 2, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (edges) FS_HIP(hipMemcpyAsync(e8h + o, e8d + o, px, hipMemcpyDeviceToHost, ctx->out_stream));
+            } else {
+                if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+            }
+            return 0;
+        };
         if (early) hook = [&](int stage) -> int {
+            if (stage == 1 && narrow_patches_edges()) return -1;
             FS_HIP(hipEventRecord(ctx->early_events[stage], ctx->stream));
             FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->early_events[stage], 0));
             if (stage == 0) {
@@ -1264,8 +1403,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                 if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
                 if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
             } else {
-                if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
-                if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+                if (download_patches_edges()) return -1;
             }
             return 0;
         };
@@ -1274,20 +1412,40 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                               ctx->points.as<float>() + f0 * N * 3, ctx->patches64.as<int64_t>() + f0 * N,
                               ctx->edges.as<int32_t>() + f0 * N, ctx->surfaces64.as<int64_t>() + f0 * N,
                               num_surfaces ? num_surfaces + f0 : nullptr, hook))
-            return drained();
+            return drained_all();
+        if (narrow) {
+            if (!early && narrow_patches_edges()) return drained_all();
+            if (surfaces) {
+                const size_t n4 = px / 4;
+                hipLaunchKernelGGL(narrow_surfaces_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   ctx->surfaces64.as<int64_t>() + o, s16d + o, n4);
+                FS_HIP(hipGetLastError());
+            }
+        }
         FS_HIP(hipEventRecord(ctx->pipe_events[2 * k + 1], ctx->stream));
         FS_HIP(hipStreamWaitEvent(ctx->out_stream, ctx->pipe_events[2 * k + 1], 0));
         if (!early) {
             if (angles) FS_HIP(hipMemcpyAsync(angles + o * 2, ctx->angles.as<float>() + o * 2, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
             if (vectors) FS_HIP(hipMemcpyAsync(vectors + o * 3, ctx->normals.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
             if (points) FS_HIP(hipMemcpyAsync(points + o * 3, ctx->points.as<float>() + o * 3, px * 12, hipMemcpyDeviceToHost, ctx->out_stream));
-            if (patches) FS_HIP(hipMemcpyAsync(patches + o, ctx->patches64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
-            if (edges) FS_HIP(hipMemcpyAsync(edges + o, ctx->edges.as<int32_t>() + o, px * 4, hipMemcpyDeviceToHost, ctx->out_stream));
+            if (download_patches_edges()) return drained_all();
         }
-        if (surfaces) FS_HIP(hipMemcpyAsync(surfaces + o, ctx->surfaces64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+        if (narrow) {
+            if (surfaces) FS_HIP(hipMemcpyAsync(s16h + o, s16d + o, px * 2, hipMemcpyDeviceToHost, ctx->out_stream));
+            FS_HIP(hipEventRecord(ctx->narrow_events[k], ctx->out_stream));
+            {
+                std::lock_guard<std::mutex> lk(jobs.m);
+                jobs.posted = k + 1;
+            }
+            jobs.cv.notify_all();
+        } else if (surfaces) {
+            FS_HIP(hipMemcpyAsync(surfaces + o, ctx->surfaces64.as<int64_t>() + o, px * 8, hipMemcpyDeviceToHost, ctx->out_stream));
+        }
     }
+    finish_workers(true);
     FS_HIP(hipStreamSynchronize(ctx->out_stream));
     FS_HIP(hipStreamSynchronize(ctx->stream));
+    if (jobs.failed) return ctx->fail("fs_find_surfaces: a worker thread could not wait for its chunk's copies");
     return 0;
 }
 

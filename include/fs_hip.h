@@ -136,8 +136,11 @@ int fs_crf_step_lr(fs_ctx *ctx, int B, int h, int w, int S, const float *unary, 
  * num_surfaces[n] = max(patches)+1.  Any output pointer may be NULL.
  * Host pointers; returns when every output has arrived.  More than 16 frames go through in chunks of 16 whose
  * copies run beside the kernels of the neighbouring chunks (page-locked arrays make them DMA transfers:
- * fs_host_alloc); a call of up to 16 frames sends each group of outputs on its way as soon as the kernels that
- * complete it are enqueued, and copies inputs that arrive in pageable memory into page-locked memory first. */
+ * fs_host_alloc); such a call sends patches and surfaces as 16-bit and depth_edges as 8-bit images over the link and
+ * widens them into the caller's int64 / int32 arrays on a few worker threads of its own (the link bounds this entry
+ * point, and the label images are 6.2 of a 640x480 frame's 15.8 MB as they are, 1.5 MB narrow).  A call of up to 16
+ * frames sends each group of outputs on its way as soon as the kernels that complete it are enqueued, and copies
+ * inputs that arrive in pageable memory into page-locked memory first. */
 int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint8_t *rgb, float *angles,
                            float *vectors, float *points, int64_t *patches, int32_t *edges, int64_t *surfaces,
                            int32_t *num_surfaces);

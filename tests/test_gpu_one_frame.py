@@ -181,6 +181,47 @@ def test_small_host_calls_with_and_without_early_downloads():
                 _same(ctx.find_surfaces_batch(depth[i], rgb[i]), {k: ref[k][i] for k in KEYS + ("num_surfaces",)}, f"{what}, frame {i}")
 
 
+def test_large_host_calls_with_and_without_narrow_label_downloads():
+    """A host-buffer call of several chunks (more than 16 frames) sends patches and surfaces as 16-bit and depth edges as 8-bit
+    images and widens them into the caller's arrays on worker threads; the arrays it fills are those of a context that copies
+    the int64 / int32 images as they are, with a last chunk that is not full, with one worker thread and with many, and when
+    the caller wants only some of the label images."""
+    import ctypes
+    from imagesegmentation_amd import _lib
+    from imagesegmentation_amd._lib import Context
+    from imagesegmentation_amd.synth import make_batch
+    H, W, n = 96, 128, 37                                    # chunks of 16, 16 and 5 frames
+    d, c = make_batch(list(range(200, 200 + n)), H, W)
+
+    def context(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return Context(H, W, max_batch=n)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    with context(FS_NO_NARROW_DOWNLOADS="1") as plain, context() as narrow, context(FS_WIDEN_THREADS="1") as one, \
+            context(FS_WIDEN_THREADS="13") as many:
+        ref = plain.find_surfaces_batch(d, c)
+        assert ref["surfaces"].max() > 0 and ref["depth_edges"].max() == 1
+        for ctx, what in ((narrow, "narrow"), (one, "one worker"), (many, "thirteen workers")):
+            _same(ctx.find_surfaces_batch(d, c), ref, what)
+            _same(ctx.find_surfaces_batch(d[:17], c[:17]), {k: ref[k][:17] for k in KEYS + ("num_surfaces",)}, what + ", 17 frames")
+        # only the final labels wanted: the other outputs are null pointers
+        lib = _lib.load()
+        sur = np.full((n, H, W), -1, np.int64)
+        ns = np.zeros(n, np.int32)
+        null = ctypes.c_void_p()
+        rc = lib.fs_find_surfaces_batch(narrow._h, n, _lib._ptr(d), _lib._ptr(c), null, null, null, null, null, _lib._ptr(sur), _lib._ptr(ns))
+        assert rc == 0, lib.fs_last_error(narrow._h)
+        assert np.array_equal(sur, ref["surfaces"]) and np.array_equal(ns, ref["num_surfaces"])
+
+
 def test_results_do_not_depend_on_what_freed_memory_held():
     """Device memory that the process has freed comes back from the allocator with its old contents.  A context's
     buffers start as zeros all the same: fill a gigabyte with all-ones bytes (NaN as floats), free it, create a
