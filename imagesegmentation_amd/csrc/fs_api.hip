@@ -1337,6 +1337,7 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
         }
         const int device = ctx->device;
         std::vector<hipEvent_t> *events = &ctx->narrow_events;
+        try {
         for (int t = 0; t < parts; ++t)
             workers.emplace_back([&jobs, events, device, chunks, parts, C, n, N, p16h, s16h, e8h, patches, surfaces, edges]() {
                 if (hipSetDevice(device) != hipSuccess) jobs.failed = 1;
@@ -1357,6 +1358,10 @@ int fs_find_surfaces_batch(fs_ctx *ctx, int n, const uint16_t *depth, const uint
                     if (edges) widen_u8_to_i32(e8h + lo, edges + lo, hi - lo);
                 }
             });
+        } catch (const std::exception &e) {              // (no thread to be had: nothing is in flight yet)
+            jobs.finish(false);
+            return ctx->fail(std::string("fs_find_surfaces: cannot start the worker threads: ") + e.what());
+        }
     }
     auto finish_workers = [&](bool ok) { jobs.finish(ok); };
     auto drained_all = [&]() {
