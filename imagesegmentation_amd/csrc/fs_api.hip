@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <immintrin.h>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -72,7 +73,7 @@ struct fs_ctx {
     // copies of a chunk's int64 / int32 images) to page-locked staging (narrow_host) and widen them into the caller's
     // arrays on worker threads: 1.5 instead of 6.2 MB of a frame's 15.8 cross the link, which bounds that entry point.
     bool narrow_downloads = true;                  // FS_NO_NARROW_DOWNLOADS=1 switches that off (measurements)
-    int widen_threads = 4;                         // FS_WIDEN_THREADS
+    int widen_threads = 3;                         // FS_WIDEN_THREADS (two already keep up with the link)
     DevBuf narrow_dev;
     HostBuf narrow_host;
     std::vector<hipEvent_t> narrow_events;         // per chunk: its narrow images have arrived
@@ -490,13 +491,45 @@ __global__ __launch_bounds__(256) void narrow_surfaces_kernel(const int64_t *__r
     const longlong2 a = reinterpret_cast<const longlong2 *>(surfaces)[2 * i], b = reinterpret_cast<const longlong2 *>(surfaces)[2 * i + 1];
     reinterpret_cast<short4 *>(s16)[i] = make_short4((short)a.x, (short)a.y, (short)b.x, (short)b.y);
 }
-// host side: back to the caller's int64 / int32 arrays (plain loops; the compiler vectorises the sign extension)
+// host side: back to the caller's int64 / int32 arrays.  The wide arrays are written once and not read here, so on a CPU
+// with AVX2 the stores bypass the cache (a plain store first reads the line it is about to overwrite: twice the memory
+// traffic, and with one process per GPU on a node the host's memory is what all of them share).
+__attribute__((target("avx2"))) void widen_i16_to_i64_avx2(const int16_t *src, int64_t *dst, size_t n)
+{
+    size_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u); ++i) dst[i] = src[i];
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 8));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), _mm256_cvtepi16_epi64(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 4), _mm256_cvtepi16_epi64(_mm_srli_si128(a, 8)));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 8), _mm256_cvtepi16_epi64(b));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 12), _mm256_cvtepi16_epi64(_mm_srli_si128(b, 8)));
+    }
+    for (; i < n; ++i) dst[i] = src[i];
+    _mm_sfence();
+}
+__attribute__((target("avx2"))) void widen_u8_to_i32_avx2(const uint8_t *src, int32_t *dst, size_t n)
+{
+    size_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31u); ++i) dst[i] = src[i];
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), _mm256_cvtepu8_epi32(a));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 8), _mm256_cvtepu8_epi32(_mm_srli_si128(a, 8)));
+    }
+    for (; i < n; ++i) dst[i] = src[i];
+    _mm_sfence();
+}
+const bool g_cpu_has_avx2 = __builtin_cpu_supports("avx2");
 void widen_i16_to_i64(const int16_t *src, int64_t *dst, size_t n)
 {
+    if (g_cpu_has_avx2) return widen_i16_to_i64_avx2(src, dst, n);
     for (size_t i = 0; i < n; ++i) dst[i] = src[i];
 }
 void widen_u8_to_i32(const uint8_t *src, int32_t *dst, size_t n)
 {
+    if (g_cpu_has_avx2) return widen_u8_to_i32_avx2(src, dst, n);
     for (size_t i = 0; i < n; ++i) dst[i] = src[i];
 }
 // The worker threads of one host-buffer call: chunk k's narrow images may be widened once the main thread has recorded the
