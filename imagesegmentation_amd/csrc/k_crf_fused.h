@@ -284,7 +284,7 @@ __device__ __forceinline__ void fused_accumulate(float (&acc)[2][8], const float
 #if FS_TILE_CLOCKS
 // experiment build: cycles that the first lane of every block spent in the phases of the tiles it worked on
 // (fs_debug_phase_clocks in k_crf_fused_r7.hip reads and clears them; tools/phase_clocks.py)
-__device__ unsigned long long g_phase_clocks[8];
+__device__ unsigned long long g_phase_clocks[12];
 #define FS_PHASE(i) do { if (threadIdx.x == 0) { const unsigned long long t_now = __builtin_readcyclecounter(); ph[i] += t_now - t_last; t_last = t_now; } } while (0)
 #else
 #define FS_PHASE(i) do { } while (0)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     __builtin_amdgcn_s_setprio(2);
     __syncthreads();
 #if FS_TILE_CLOCKS
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
 #endif
   for (;;) {
     const unsigned tile_id = s_ticket;
@@ -357,6 +357,10 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
     const int by = brem / tiles_x, bx = brem - by * tiles_x;
     const CrfFrameDesc d = descs[bz];
     const int r = R ? R : g.r, S = frame_channels(d, NCH * CH);
+#if FS_TILE_CLOCKS
+    asm volatile("" :: "s"(S));
+    FS_PHASE(8);                                            // ticket and descriptor
+#endif
     // (a tile outside the launch's range of listed labels belongs to another launch of the same update)
     const int tile_labels = global_ptr(d.tile_recs)[((size_t)by * tiles_x + bx) * TILE_REC];
     if (S == 0 || tile_labels < a_min || tile_labels > a_max) {   // S == 0: enqueued ahead of the label count, and the frame does not fit
@@ -445,6 +449,9 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
         if (tid < 15 * MASK_WORDS) s_nmask[tid] = nb_word;
         store_features(tid, fa, fb);
     }
+#if FS_TILE_CLOCKS
+    FS_PHASE(9);                                            // own code up to the barrier
+#endif
     const bool wave_work = __ballot(any_work) != 0ull;
     // a tile without a single valid depth (about one in five on sensor data) only writes the override values:
     // nothing more is staged for it
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void crf_iter_fused_kernel(const CrfFrameDe
   }
 #if FS_TILE_CLOCKS
     if (threadIdx.x == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_clocks[i], ph[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_phase_clocks[i], ph[i]);
 #endif
 }
 template <int R, int TH, int NCH, int MODE, bool UNIFORM = false, bool TRACE = false>

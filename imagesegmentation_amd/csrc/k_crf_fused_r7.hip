@@ -21,11 +21,11 @@ hipError_t launch_fused_r7_uniform(int channel_class, const FusedLaunch &L)
 
 #if FS_TILE_CLOCKS
 // experiment build only: the phase clocks of every r = 7 update since the last call (k_crf_fused.h), then cleared
-extern "C" __attribute__((visibility("default"))) int fs_debug_phase_clocks(unsigned long long out[8])
+extern "C" __attribute__((visibility("default"))) int fs_debug_phase_clocks(unsigned long long out[12])
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fs::g_phase_clocks), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fs::g_phase_clocks), 12 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    const unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(fs::g_phase_clocks), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -22,7 +22,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 111
     depth, rgb, _ = bench.load_frames("osd", n, 0, 1, 0)
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 12)()
     with _lib.Context(depth.shape[1], depth.shape[2], max_batch=len(depth)) as ctx:
         ctx.find_surfaces_batch(depth, rgb)
         lib.fs_debug_phase_clocks(out)
@@ -37,6 +37,10 @@ def main():
     for name, c in zip(NAMES, v[:6]):
         print(f"  {name:48s} {c / work:9.0f} cycles per worked tile  {c / work / 2400:6.2f} us  {100 * c / total:5.1f} %")
     print(f"  {'sum':48s} {total / work:9.0f} cycles  {total / work / 2400:6.2f} us")
+    if v[8] or v[9]:
+        print(f"  of the first phase: ticket and descriptor {v[8] / work / 2400:5.2f} us, own code up to the barrier {v[9] / work / 2400:5.2f} us, "
+              f"waiting at the barrier {v[0] / work / 2400:5.2f} us")
+        print(f"  (the first phase's line above is then the barrier wait alone; the three add up to {(v[0] + v[8] + v[9]) / work / 2400:5.2f} us)")
 
 
 if __name__ == "__main__":
