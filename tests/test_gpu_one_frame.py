@@ -212,6 +212,10 @@ def test_large_host_calls_with_and_without_narrow_label_downloads():
         for ctx, what in ((narrow, "narrow"), (one, "one worker"), (many, "thirteen workers")):
             _same(ctx.find_surfaces_batch(d, c), ref, what)
             _same(ctx.find_surfaces_batch(d[:17], c[:17]), {k: ref[k][:17] for k in KEYS + ("num_surfaces",)}, what + ", 17 frames")
+        # a frame's arrays do not depend on its place in the call (another chunk, another worker's part of the chunk)
+        perm = np.arange(n)[::-1].copy()
+        rev = narrow.find_surfaces_batch(d[perm], c[perm])
+        _same({k: np.asarray(rev[k])[perm] for k in KEYS + ("num_surfaces",)}, ref, "frames in reverse order")
         # only the final labels wanted: the other outputs are null pointers
         lib = _lib.load()
         sur = np.full((n, H, W), -1, np.int64)
